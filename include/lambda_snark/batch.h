@@ -1,0 +1,93 @@
+/*
+ * lambda_snark/batch.h — ADDITIVE entry points (not in the reference): batched and device-resident
+ * forms of the hot path, seeded/deterministic variants, and introspection.
+ *
+ * Why they exist: the reference C-ABI moves ONE polynomial through host pointers per call
+ * (cpp-core/include/lambda_snark/ntt.h:55-92, commitment.h:58-63); a GPU cannot reach the headline
+ * metric (batched degree-2^16 NTTs/s, commits/s) through that, so SURVEY.md §8(b) asks for batched
+ * twins.  Every symbol here is `lsr_`-prefixed or `*_batch`-suffixed; the reference symbols keep their
+ * exact semantics.  All are extern "C", plain pointers and sizes; `stream` is a hipStream_t passed as
+ * void* (NULL = the default stream of the context's device).
+ */
+#pragma once
+
+#include "lambda_snark/commitment.h"
+#include "lambda_snark/ntt.h"
+#include "lambda_snark/types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- runtime ---------------- */
+/* number of visible HIP devices (0 when there is no GPU / no driver) */
+int lsr_device_count(void) LSR_NOEXCEPT;
+/* last error message of the calling thread ("" if none) */
+const char* lsr_last_error(void) LSR_NOEXCEPT;
+/* library / kernel-variant description, e.g. "lambda_snark_core hip gfx950 v1" */
+const char* lsr_version(void) LSR_NOEXCEPT;
+
+/* ---------------- NTT: contexts on a chosen device ---------------- */
+/* like ntt_context_create, on HIP device `device` (-1 = LAMBDA_SNARK_DEVICE env, else LOCAL_RANK, else 0) */
+NttContext* lsr_ntt_context_create_on(uint64_t q, uint32_t n, int device) LSR_NOEXCEPT;
+int      lsr_ntt_context_device(const NttContext* ctx) LSR_NOEXCEPT;
+uint64_t lsr_ntt_context_root(const NttContext* ctx) LSR_NOEXCEPT;   /* psi */
+/* 1 if the context computes with the exact FP64-FMA Barrett kernels (q < 2^45), 0 for u64 Shoup */
+int      lsr_ntt_context_uses_f64(const NttContext* ctx) LSR_NOEXCEPT;
+/* force the arithmetic flavour of FUTURE contexts: 0 auto, 1 u64 Shoup always (testing) */
+void     lsr_set_arith_mode(int mode) LSR_NOEXCEPT;
+
+/* ---------------- NTT: batched, host buffers ([batch][n] contiguous) ---------------- */
+int ntt_forward_batch(const NttContext* ctx, uint64_t* polys, size_t batch) LSR_NOEXCEPT;
+int ntt_inverse_batch(const NttContext* ctx, uint64_t* polys, size_t batch) LSR_NOEXCEPT;
+/* result/a/b are [batch][n]; returns 0 / -1 (unlike the void single-poly form) */
+int ntt_mul_pointwise_batch(const NttContext* ctx, uint64_t* result, const uint64_t* a, const uint64_t* b,
+                            size_t batch) LSR_NOEXCEPT;
+
+/* ---------------- NTT: batched, device-resident, asynchronous on `stream` ---------------- */
+int lsr_ntt_forward_batch_device(const NttContext* ctx, uint64_t* d_polys, size_t batch, void* stream) LSR_NOEXCEPT;
+int lsr_ntt_inverse_batch_device(const NttContext* ctx, uint64_t* d_polys, size_t batch, void* stream) LSR_NOEXCEPT;
+int lsr_ntt_mul_pointwise_device(const NttContext* ctx, uint64_t* d_result, const uint64_t* d_a,
+                                 const uint64_t* d_b, size_t count, void* stream) LSR_NOEXCEPT;
+
+/* ---------------- Gaussian sampler: seeded / device ---------------- */
+/* sample i of object (seed, domain, index) uses ChaCha20 stream words 2i (magnitude) and 2i+1 (sign);
+ * output = two's-complement int64 like sample_gaussian. Host buffer. */
+int lsr_sample_gaussian_seeded(uint64_t* output, size_t len, double sigma, uint64_t seed, uint32_t domain,
+                               uint64_t index) LSR_NOEXCEPT;
+/* CDT table exactly as cpp-core/src/utils.cpp:26-75 (host long double); returns entry count or 0 */
+size_t lsr_gaussian_cdf(double sigma, uint64_t* cdf, size_t cap) LSR_NOEXCEPT;
+
+/* ---------------- commitment: seeded contexts, batches, the metric workload ---------------- */
+/* lwe_context_create with an explicit key seed (0 = fresh entropy) and device (-1 = default) */
+LweContext* lsr_lwe_context_create_seeded(const PublicParams* params, uint64_t key_seed, int device) LSR_NOEXCEPT;
+uint64_t lsr_lwe_modulus(const LweContext* ctx) LSR_NOEXCEPT;         /* internal q actually used */
+uint64_t lsr_lwe_plain_modulus(const LweContext* ctx) LSR_NOEXCEPT;   /* t */
+uint32_t lsr_lwe_ring_degree(const LweContext* ctx) LSR_NOEXCEPT;
+uint32_t lsr_lwe_module_rank(const LweContext* ctx) LSR_NOEXCEPT;
+size_t   lsr_lwe_commitment_words(const LweContext* ctx) LSR_NOEXCEPT; /* LweCommitment.len */
+const NttContext* lsr_lwe_ntt_context(const LweContext* ctx) LSR_NOEXCEPT;
+/* copy the public matrix A_hat ([k][k][n], NTT domain) to a host buffer */
+int lsr_lwe_public_matrix(const LweContext* ctx, uint64_t* a_hat) LSR_NOEXCEPT;
+
+/* `batch` commitments in one device pass.  messages = [batch][msg_len]; seeds[batch] (0 = fresh);
+ * out[batch] receives commitments to be freed with lwe_commitment_free.  0 / -1. */
+int lwe_commit_batch(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch,
+                     const uint64_t* seeds, LweCommitment** out) LSR_NOEXCEPT;
+
+/* The Module-LWE matrix–vector workload of BASELINE config 3, device-resident:
+ *   u_j = INTT( A_hat^T . NTT(r_j) ) + e1_j   for j < batch;   r, e1, u are [batch][k][n] in [0,q).
+ * d_e1 == NULL: e1 is sampled on the device from (seeds[j], domain 5, component) — seeds is then a
+ * DEVICE-or-host pointer? no: a HOST array of `batch` seeds (copied asynchronously).
+ * d_r is overwritten (used as NTT workspace) unless d_r_scratch is given. */
+int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u,
+                                 size_t batch, const uint64_t* seeds, void* stream) LSR_NOEXCEPT;
+
+/* ---------------- host-only number theory (usable without a GPU) ---------------- */
+uint64_t lsr_minimal_primitive_root(uint64_t q, uint32_t n) LSR_NOEXCEPT;   /* 0 if none */
+uint64_t lsr_select_commit_modulus(uint64_t requested_q, uint32_t n) LSR_NOEXCEPT;
+uint64_t lsr_plain_modulus(uint32_t n) LSR_NOEXCEPT;                        /* SEAL Batching(n,20) */
+
+#ifdef __cplusplus
+}
+#endif

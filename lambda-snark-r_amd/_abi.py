@@ -1,0 +1,122 @@
+"""ctypes binding of liblambda_snark_core.so — the stub a maintainer of lambda-snark-sys would mirror.
+
+The library is the product; this file only declares its C-ABI (include/lambda_snark/*.h).  There is no
+CPU fallback: if the shared library is missing the import fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblambda_snark_core.so")
+
+u64 = ctypes.c_uint64
+u32 = ctypes.c_uint32
+c_int = ctypes.c_int
+c_size = ctypes.c_size_t
+c_double = ctypes.c_double
+vp = ctypes.c_void_p
+u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class PublicParams(ctypes.Structure):
+    """reference cpp-core/include/lambda_snark/types.h:60-67"""
+    _fields_ = [
+        ("profile", ctypes.c_int),
+        ("security_level", ctypes.c_uint32),
+        ("modulus", ctypes.c_uint64),
+        ("ring_degree", ctypes.c_uint32),
+        ("module_rank", ctypes.c_uint32),
+        ("sigma", ctypes.c_double),
+    ]
+
+
+class LweCommitment(ctypes.Structure):
+    """reference types.h:36-39"""
+    _fields_ = [("data", u64p), ("len", ctypes.c_size_t)]
+
+
+class LweOpening(ctypes.Structure):
+    """reference types.h:44-47"""
+    _fields_ = [("randomness", u64p), ("rand_len", ctypes.c_size_t)]
+
+
+PROFILE_SCALAR_A = 0
+PROFILE_RING_B = 1
+
+# every symbol declared in include/lambda_snark/*.h: name -> (restype, argtypes)
+SIGNATURES = {
+    # ntt.h
+    "ntt_context_create": (vp, [u64, u32]),
+    "ntt_context_free": (None, [vp]),
+    "ntt_forward": (c_int, [vp, vp, u32]),
+    "ntt_inverse": (c_int, [vp, vp, u32]),
+    "ntt_mul_pointwise": (None, [vp, vp, vp, vp, u32]),
+    # commitment.h
+    "lwe_context_create": (vp, [ctypes.POINTER(PublicParams)]),
+    "lwe_context_free": (None, [vp]),
+    "lwe_commit": (ctypes.POINTER(LweCommitment), [vp, vp, c_size, u64]),
+    "lwe_commitment_free": (None, [ctypes.POINTER(LweCommitment)]),
+    "lwe_commitment_clone": (ctypes.POINTER(LweCommitment), [ctypes.POINTER(LweCommitment)]),
+    "lwe_verify_opening": (c_int, [vp, ctypes.POINTER(LweCommitment), vp, c_size, ctypes.POINTER(LweOpening)]),
+    "lwe_linear_combine": (ctypes.POINTER(LweCommitment), [vp, ctypes.POINTER(ctypes.POINTER(LweCommitment)), vp, c_size]),
+    # utils.h
+    "sample_gaussian": (c_int, [vp, c_size, c_double]),
+    # batch.h
+    "lsr_device_count": (c_int, []),
+    "lsr_last_error": (ctypes.c_char_p, []),
+    "lsr_version": (ctypes.c_char_p, []),
+    "lsr_ntt_context_create_on": (vp, [u64, u32, c_int]),
+    "lsr_ntt_context_device": (c_int, [vp]),
+    "lsr_ntt_context_root": (u64, [vp]),
+    "lsr_ntt_context_uses_f64": (c_int, [vp]),
+    "lsr_set_arith_mode": (None, [c_int]),
+    "ntt_forward_batch": (c_int, [vp, vp, c_size]),
+    "ntt_inverse_batch": (c_int, [vp, vp, c_size]),
+    "ntt_mul_pointwise_batch": (c_int, [vp, vp, vp, vp, c_size]),
+    "lsr_ntt_forward_batch_device": (c_int, [vp, vp, c_size, vp]),
+    "lsr_ntt_inverse_batch_device": (c_int, [vp, vp, c_size, vp]),
+    "lsr_ntt_mul_pointwise_device": (c_int, [vp, vp, vp, vp, c_size, vp]),
+    "lsr_sample_gaussian_seeded": (c_int, [vp, c_size, c_double, u64, u32, u64]),
+    "lsr_gaussian_cdf": (c_size, [c_double, vp, c_size]),
+    "lsr_lwe_context_create_seeded": (vp, [ctypes.POINTER(PublicParams), u64, c_int]),
+    "lsr_lwe_modulus": (u64, [vp]),
+    "lsr_lwe_plain_modulus": (u64, [vp]),
+    "lsr_lwe_ring_degree": (u32, [vp]),
+    "lsr_lwe_module_rank": (u32, [vp]),
+    "lsr_lwe_commitment_words": (c_size, [vp]),
+    "lsr_lwe_ntt_context": (vp, [vp]),
+    "lsr_lwe_public_matrix": (c_int, [vp, vp]),
+    "lwe_commit_batch": (c_int, [vp, vp, c_size, c_size, vp, ctypes.POINTER(ctypes.POINTER(LweCommitment))]),
+    "lsr_mlwe_matvec_batch_device": (c_int, [vp, vp, vp, vp, c_size, vp, vp]),
+    "lsr_minimal_primitive_root": (u64, [u64, u32]),
+    "lsr_select_commit_modulus": (u64, [u64, u32]),
+    "lsr_plain_modulus": (u64, [u32]),
+}
+
+
+def load_library(path=None):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load_library()
+    return _lib
+
+
+def last_error():
+    return lib().lsr_last_error().decode()

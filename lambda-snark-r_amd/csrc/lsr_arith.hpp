@@ -1,0 +1,174 @@
+// Device arithmetic for residues mod q — two flavours behind one butterfly interface.
+//
+//  * ArithF64 (q < 2^45): residues are kept as IEEE doubles holding exact integers.  A modular product
+//    is an exact FP64-FMA Barrett reduction (6 full-rate v_*_f64 instructions, no integer multiplies):
+//        h = x*w            (rounded high part)          l = fma(x, w, -h)   (exact low part)
+//        k = rint(h / q)    (via h * (1/q))              r = fma(-k, q, h) + l
+//    r == x*w (mod q) EXACTLY, with |r| <= ~0.75 q, provided |x * w / q| < 2^49 (DESIGN.md "Exactness
+//    of the f64 path").  Forward CT butterflies need no per-stage correction (|value| grows by < q
+//    per stage, 18 q < 2^50 for q < 2^45); inverse GS butterflies re-centre the sum path once per
+//    radix-16 round.  The final store maps to the canonical representative in [0,q), so the result
+//    is bit-identical to the reference's Harvey/Shoup arithmetic (ntt.cpp:84,99 via SEAL).
+//    Measured on MI355X (tools/ubench_arith.hip): 42 cycles per wave-butterfly vs 99 for u64 Shoup.
+//  * ArithU64 (any q < 2^61): SEAL's lazy Harvey butterflies with Shoup multiplication, values in
+//    [0,4q) forward / [0,2q) inverse — the restated reference algorithm itself.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace lsr {
+
+struct ModParams {
+    uint64_t q;        // modulus
+    uint64_t two_q;    // 2q
+    double qd;         // (double) q
+    double inv_qd;     // 1.0 / q rounded to nearest
+    uint64_t n_inv;    // n^-1 mod q
+    uint64_t n_inv_shoup;
+    uint64_t barrett_hi, barrett_lo;   // floor(2^128 / q) for the pointwise kernel
+    int logn;
+};
+
+// ---------------------------------------------------------------------------------------------
+// exact conversions u64 <-> f64 for integers below 2^52 (one integer op + one FP add each)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double f64_from_u52(uint64_t x) {
+    const uint64_t bits = (x & 0x000FFFFFFFFFFFFFull) | 0x4330000000000000ull;   // 2^52 + x
+    return __longlong_as_double((long long)bits) - 4503599627370496.0;
+}
+__device__ __forceinline__ uint64_t u52_from_f64(double v) {   // v an integer in [0, 2^52)
+    return (uint64_t)__double_as_longlong(v + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
+}
+
+__device__ __forceinline__ double mulmod_f64(double x, double w, double q, double inv_q) {
+    const double h = x * w;
+    const double l = __builtin_fma(x, w, -h);
+    const double k = __builtin_rint(h * inv_q);
+    const double d = __builtin_fma(-k, q, h);
+    return d + l;
+}
+// bring |v| < 2^50 back to |r| <= q/2 (+1)
+__device__ __forceinline__ double recentre_f64(double v, double q, double inv_q) {
+    const double k = __builtin_rint(v * inv_q);
+    return __builtin_fma(-k, q, v);
+}
+__device__ __forceinline__ double canonical_f64(double v, double q, double inv_q) {
+    double r = recentre_f64(v, q, inv_q);
+    return r < 0.0 ? r + q : r;
+}
+
+struct ArithF64 {
+    using elem = double;     // residue (exact integer in a double)
+    using twid = double;     // twiddle (canonical, as double)
+    struct Tables {          // device pointers, stage order (entry m+i)
+        const double* fwd;
+        const double* inv;
+    };
+    static constexpr int kTwiddleWords = 1;
+
+    static __device__ __forceinline__ elem load(uint64_t x, const ModParams&) { return f64_from_u52(x); }
+    static __device__ __forceinline__ uint64_t store_canonical(elem v, const ModParams& p) {
+        return u52_from_f64(canonical_f64(v, p.qd, p.inv_qd));
+    }
+    // value already known to satisfy |v| < q (a fresh mulmod result)
+    static __device__ __forceinline__ uint64_t store_reduced(elem v, const ModParams& p) {
+        return u52_from_f64(v < 0.0 ? v + p.qd : v);
+    }
+    static __device__ __forceinline__ twid load_tw(const double* table, uint32_t idx) { return table[idx]; }
+
+    // Cooley–Tukey: (x, y) <- (x + w y, x - w y)
+    static __device__ __forceinline__ void ct(elem& x, elem& y, twid w, const ModParams& p) {
+        const double t = mulmod_f64(y, w, p.qd, p.inv_qd);
+        const double a = x;
+        x = a + t;
+        y = a - t;
+    }
+    // Gentleman–Sande: (x, y) <- (x + y, (x - y) w)
+    static __device__ __forceinline__ void gs(elem& x, elem& y, twid w, const ModParams& p) {
+        const double a = x, b = y;
+        x = a + b;
+        y = mulmod_f64(a - b, w, p.qd, p.inv_qd);
+    }
+    // last inverse stage with n^-1 folded in: (x, y) <- ((x + y) ninv, (x - y) (w ninv))
+    static __device__ __forceinline__ void gs_scaled(elem& x, elem& y, twid w_scaled, twid n_inv, const ModParams& p) {
+        const double a = x, b = y;
+        x = mulmod_f64(a + b, n_inv, p.qd, p.inv_qd);
+        y = mulmod_f64(a - b, w_scaled, p.qd, p.inv_qd);
+    }
+    static __device__ __forceinline__ void end_of_forward_round(elem&, const ModParams&) {}
+    static __device__ __forceinline__ void end_of_inverse_round(elem& v, const ModParams& p) { v = recentre_f64(v, p.qd, p.inv_qd); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// u64 Harvey / Shoup (SEAL dwthandler.h Arithmetic<uint64_t, MultiplyUIntModOperand, ...>)
+// ---------------------------------------------------------------------------------------------
+struct ShoupOperand {
+    uint64_t w, wq;
+};
+
+__device__ __forceinline__ uint64_t mul_shoup_lazy(uint64_t x, ShoupOperand o, uint64_t q) {
+    return x * o.w - __umul64hi(x, o.wq) * q;   // in [0, 2q)
+}
+
+struct ArithU64 {
+    using elem = uint64_t;
+    using twid = ShoupOperand;
+    struct Tables {
+        const ShoupOperand* fwd;
+        const ShoupOperand* inv;
+    };
+    static constexpr int kTwiddleWords = 2;
+
+    static __device__ __forceinline__ elem load(uint64_t x, const ModParams&) { return x; }
+    static __device__ __forceinline__ uint64_t store_canonical(elem v, const ModParams& p) {
+        if (v >= p.two_q) v -= p.two_q;
+        if (v >= p.q) v -= p.q;
+        return v;
+    }
+    static __device__ __forceinline__ uint64_t store_reduced(elem v, const ModParams& p) { return v >= p.q ? v - p.q : v; }
+    static __device__ __forceinline__ twid load_tw(const ShoupOperand* table, uint32_t idx) { return table[idx]; }
+
+    static __device__ __forceinline__ void ct(elem& x, elem& y, twid w, const ModParams& p) {
+        const uint64_t u = x >= p.two_q ? x - p.two_q : x;
+        const uint64_t v = mul_shoup_lazy(y, w, p.q);
+        x = u + v;
+        y = u + p.two_q - v;
+    }
+    static __device__ __forceinline__ void gs(elem& x, elem& y, twid w, const ModParams& p) {
+        const uint64_t u = x, v = y;
+        const uint64_t s = u + v;
+        x = s >= p.two_q ? s - p.two_q : s;
+        y = mul_shoup_lazy(u + p.two_q - v, w, p.q);
+    }
+    static __device__ __forceinline__ void gs_scaled(elem& x, elem& y, twid w_scaled, twid n_inv, const ModParams& p) {
+        const uint64_t u = x >= p.two_q ? x - p.two_q : x, v = y;
+        uint64_t s = u + v;
+        s = s >= p.two_q ? s - p.two_q : s;
+        x = mul_shoup_lazy(s, n_inv, p.q);
+        y = mul_shoup_lazy(u + p.two_q - v, w_scaled, p.q);
+    }
+    static __device__ __forceinline__ void end_of_forward_round(elem&, const ModParams&) {}
+    static __device__ __forceinline__ void end_of_inverse_round(elem&, const ModParams&) {}
+};
+
+// canonical (a*b) mod q for ANY 64-bit a, b (q < 2^61): 128-bit product + Barrett with floor(2^128/q)
+// (same contract as SEAL multiply_uint_mod used at ntt.cpp:117).
+__device__ __forceinline__ uint64_t mulmod_barrett128(uint64_t a, uint64_t b, const ModParams& p) {
+    const uint64_t lo = a * b, hi = __umul64hi(a, b);
+    // q_hat = floor( (hi:lo) * (bhi:blo) / 2^128 ), using the three significant partial products
+    const uint64_t c1 = __umul64hi(lo, p.barrett_lo);
+    const uint64_t m1_lo = lo * p.barrett_hi, m1_hi = __umul64hi(lo, p.barrett_hi);
+    const uint64_t m2_lo = hi * p.barrett_lo, m2_hi = __umul64hi(hi, p.barrett_lo);
+    uint64_t s = c1 + m1_lo;
+    uint64_t carry = s < c1;
+    const uint64_t s2 = s + m2_lo;
+    carry += s2 < s;
+    const uint64_t q_hat = hi * p.barrett_hi + m1_hi + m2_hi + carry;
+    uint64_t r = lo - q_hat * p.q;            // exact remainder is r, r-q or r-2q
+    if (r >= p.q) r -= p.q;
+    if (r >= p.q) r -= p.q;
+    return r;
+}
+
+}  // namespace lsr

@@ -1,0 +1,424 @@
+// NTT contexts, kernel dispatch and the ntt_* C-ABI (reference: cpp-core/src/ntt.cpp).
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "lambda_snark/batch.h"
+#include "lambda_snark/ntt.h"
+#include "lsr_ntt_kernels.hpp"
+#include "lsr_runtime.hpp"
+
+namespace lsr {
+
+// ------------------------------------------------------------------------------------------------
+// runtime plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+const char* last_error_cstr() { return g_last_error.c_str(); }
+
+static std::atomic<int> g_arith_mode{0};
+int arith_mode() { return g_arith_mode.load(); }
+
+int visible_device_count() {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+int default_device() {
+    const int count = visible_device_count();
+    if (count <= 0) return 0;
+    if (const char* s = std::getenv("LAMBDA_SNARK_DEVICE")) return std::atoi(s) % count;
+    if (const char* s = std::getenv("LOCAL_RANK")) return std::atoi(s) % count;
+    return 0;
+}
+
+DeviceGuard::DeviceGuard(int device) {
+    if (hipGetDevice(&previous_) != hipSuccess) previous_ = -1;
+    if (previous_ != device) {
+        LSR_HIP(hipSetDevice(device));
+        switched_ = true;
+    }
+}
+DeviceGuard::~DeviceGuard() {
+    if (switched_ && previous_ >= 0) (void)hipSetDevice(previous_);
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+static ModParams make_mod_params(uint64_t q, int logn, uint64_t n_inv) {
+    ModParams p{};
+    p.q = q;
+    p.two_q = 2 * q;
+    p.qd = static_cast<double>(q);
+    p.inv_qd = 1.0 / static_cast<double>(q);
+    p.n_inv = n_inv;
+    p.n_inv_shoup = shoup_quotient(n_inv, q);
+    const u128 ratio = ~static_cast<u128>(0) / q;   // floor((2^128-1)/q) == floor(2^128/q) for odd q > 1
+    p.barrett_hi = static_cast<uint64_t>(ratio >> 64);
+    p.barrett_lo = static_cast<uint64_t>(ratio);
+    p.logn = logn;
+    return p;
+}
+
+NttContext* create_ntt_context(uint64_t q, uint32_t n, int device) {
+    int logn = 0;
+    if (!ntt_params_valid(q, n, &logn)) {
+        set_last_error("ntt_context_create: (q, n) rejected: need n = 2^k in [2,131072], prime q < 2^61, q = 1 mod 2n");
+        return nullptr;
+    }
+    const uint64_t psi = minimal_primitive_root_2n(q, n);
+    if (!psi) {
+        set_last_error("ntt_context_create: no primitive 2n-th root");
+        return nullptr;
+    }
+    const int devices = visible_device_count();
+    if (devices <= 0) {
+        set_last_error("ntt_context_create: no HIP device visible — this library has no CPU fallback");
+        std::fprintf(stderr, "lambda_snark_core: no HIP device visible; the MI355X backend has no CPU fallback\n");
+        return nullptr;
+    }
+    if (device < 0) device = default_device();
+    if (device >= devices) {
+        set_last_error("ntt_context_create: device index out of range");
+        return nullptr;
+    }
+    const TwiddleTables tw = build_twiddles(q, n, logn, psi);
+    auto* ctx = new NttContext;
+    try {
+        DeviceGuard guard(device);
+        ctx->modulus = q;
+        ctx->degree = n;
+        ctx->logn = logn;
+        ctx->device = device;
+        ctx->psi = psi;
+        ctx->mod = make_mod_params(q, logn, tw.n_inv);
+        ctx->use_f64 = (q < (1ull << 45)) && arith_mode() != 1;
+        const uint64_t w_last_scaled = mulmod(tw.inv[n > 1 ? 1 : 0], tw.n_inv, q);
+        if (ctx->use_f64) {
+            std::vector<double> f(n), g(n);
+            for (uint32_t i = 0; i < n; ++i) {
+                f[i] = static_cast<double>(tw.fwd[i]);
+                g[i] = static_cast<double>(tw.inv[i]);
+            }
+            ctx->fwd_f64.upload(f);
+            ctx->inv_f64.upload(g);
+            ctx->n_inv_f64 = static_cast<double>(tw.n_inv);
+            ctx->w_last_scaled_f64 = static_cast<double>(w_last_scaled);
+        } else {
+            std::vector<ShoupOperand> f(n), g(n);
+            for (uint32_t i = 0; i < n; ++i) {
+                f[i] = ShoupOperand{tw.fwd[i], shoup_quotient(tw.fwd[i], q)};
+                g[i] = ShoupOperand{tw.inv[i], shoup_quotient(tw.inv[i], q)};
+            }
+            ctx->fwd_u64.upload(f);
+            ctx->inv_u64.upload(g);
+            ctx->n_inv_u64 = ShoupOperand{tw.n_inv, shoup_quotient(tw.n_inv, q)};
+            ctx->w_last_scaled_u64 = ShoupOperand{w_last_scaled, shoup_quotient(w_last_scaled, q)};
+        }
+        ctx->staging.allocate(3ull * n);
+        LSR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    } catch (const std::exception& e) {
+        set_last_error(std::string("ntt_context_create: ") + e.what());
+        std::fprintf(stderr, "lambda_snark_core: ntt_context_create failed: %s\n", e.what());
+        destroy_ntt_context(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+void destroy_ntt_context(NttContext* ctx) {
+    if (!ctx) return;
+    try {
+        DeviceGuard guard(ctx->device);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        ctx->staging.release();
+        ctx->fwd_f64.release();
+        ctx->inv_f64.release();
+        ctx->fwd_u64.release();
+        ctx->inv_u64.release();
+    } catch (...) {
+    }
+    delete ctx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------------------
+template <class A> struct Flavour;
+template <> struct Flavour<ArithF64> {
+    static const double* fwd(const NttContext& c) { return c.fwd_f64.ptr; }
+    static const double* inv(const NttContext& c) { return c.inv_f64.ptr; }
+    static RoundConsts<ArithF64> consts(const NttContext& c) { return {c.n_inv_f64, c.w_last_scaled_f64}; }
+};
+template <> struct Flavour<ArithU64> {
+    static const ShoupOperand* fwd(const NttContext& c) { return c.fwd_u64.ptr; }
+    static const ShoupOperand* inv(const NttContext& c) { return c.inv_u64.ptr; }
+    static RoundConsts<ArithU64> consts(const NttContext& c) { return {c.n_inv_u64, c.w_last_scaled_u64}; }
+};
+
+template <class A, int LT, bool RAW_IN, bool RAW_OUT>
+static void tile_fwd(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
+    const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
+    hipLaunchKernelGGL((ntt_tile_forward<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::fwd(c));
+}
+template <class A, int LT, bool RAW_IN, bool RAW_OUT>
+static void tile_inv(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
+    const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
+    hipLaunchKernelGGL((ntt_tile_inverse<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::inv(c),
+                       Flavour<A>::consts(c));
+}
+
+template <class A, bool INVERSE, bool RAW_IN, bool RAW_OUT>
+static void strided(const NttContext& c, uint64_t* d, size_t total, int lo, int r, hipStream_t s) {
+    const size_t groups = total >> r;
+    const unsigned grid = static_cast<unsigned>((groups + kThreads - 1) / kThreads);
+    const auto* tw = INVERSE ? Flavour<A>::inv(c) : Flavour<A>::fwd(c);
+    const auto cs = Flavour<A>::consts(c);
+    switch (r) {
+        case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs); break;
+        case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs); break;
+        case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs); break;
+        default: hipLaunchKernelGGL((ntt_strided_round<A, 4, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs); break;
+    }
+}
+
+template <class A>
+static void small_forward(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
+    switch (c.logn) {
+        case 1: tile_fwd<A, 1, false, false>(c, d, total, s); break;
+        case 2: tile_fwd<A, 2, false, false>(c, d, total, s); break;
+        case 3: tile_fwd<A, 3, false, false>(c, d, total, s); break;
+        case 4: tile_fwd<A, 4, false, false>(c, d, total, s); break;
+        case 5: tile_fwd<A, 5, false, false>(c, d, total, s); break;
+        case 6: tile_fwd<A, 6, false, false>(c, d, total, s); break;
+        case 7: tile_fwd<A, 7, false, false>(c, d, total, s); break;
+        case 8: tile_fwd<A, 8, false, false>(c, d, total, s); break;
+        case 9: tile_fwd<A, 9, false, false>(c, d, total, s); break;
+        case 10: tile_fwd<A, 10, false, false>(c, d, total, s); break;
+        case 11: tile_fwd<A, 11, false, false>(c, d, total, s); break;
+        default: tile_fwd<A, 12, false, false>(c, d, total, s); break;
+    }
+}
+template <class A>
+static void small_inverse(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
+    switch (c.logn) {
+        case 1: tile_inv<A, 1, false, false>(c, d, total, s); break;
+        case 2: tile_inv<A, 2, false, false>(c, d, total, s); break;
+        case 3: tile_inv<A, 3, false, false>(c, d, total, s); break;
+        case 4: tile_inv<A, 4, false, false>(c, d, total, s); break;
+        case 5: tile_inv<A, 5, false, false>(c, d, total, s); break;
+        case 6: tile_inv<A, 6, false, false>(c, d, total, s); break;
+        case 7: tile_inv<A, 7, false, false>(c, d, total, s); break;
+        case 8: tile_inv<A, 8, false, false>(c, d, total, s); break;
+        case 9: tile_inv<A, 9, false, false>(c, d, total, s); break;
+        case 10: tile_inv<A, 10, false, false>(c, d, total, s); break;
+        case 11: tile_inv<A, 11, false, false>(c, d, total, s); break;
+        default: tile_inv<A, 12, false, false>(c, d, total, s); break;
+    }
+}
+
+template <class A>
+static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s) {
+    const size_t total = batch << c.logn;
+    if (total == 0) return;
+    if (c.logn <= kTileLog) {
+        if (inverse) small_inverse<A>(c, d, total, s);
+        else small_forward<A>(c, d, total, s);
+        return;
+    }
+    // n > 4096: index bits [12, L) go through strided rounds (at most 4 bits each), bits [0,12) through the tile kernel
+    const int extra = c.logn - kTileLog;
+    const int r_top = std::min(4, extra);
+    const int r_low = extra - r_top;   // 0 or 1
+    if (!inverse) {
+        strided<A, false, false, true>(c, d, total, c.logn - r_top, r_top, s);
+        if (r_low) strided<A, false, true, true>(c, d, total, kTileLog, r_low, s);
+        tile_fwd<A, 12, true, false>(c, d, total, s);
+    } else {
+        tile_inv<A, 12, false, true>(c, d, total, s);
+        if (r_low) strided<A, true, true, true>(c, d, total, kTileLog, r_low, s);
+        strided<A, true, true, false>(c, d, total, c.logn - r_top, r_top, s);
+    }
+}
+
+void launch_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s) {
+    if (c.use_f64) run_ntt<ArithF64>(c, d, batch, inverse, s);
+    else run_ntt<ArithU64>(c, d, batch, inverse, s);
+    LSR_HIP(hipGetLastError());
+}
+
+void launch_pointwise(const NttContext& c, uint64_t* out, const uint64_t* a, const uint64_t* b, size_t count, hipStream_t s) {
+    if (!count) return;
+    const size_t want = (count + kThreads - 1) / kThreads;
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>(want, 256 * 16));
+    hipLaunchKernelGGL(pointwise_mul_kernel, dim3(grid), dim3(kThreads), 0, s, out, a, b, count, c.mod);
+    LSR_HIP(hipGetLastError());
+}
+
+// host-buffer transform of `batch` polynomials through bounded device chunks
+static void host_ntt(const NttContext& c, uint64_t* polys, size_t batch, bool inverse) {
+    DeviceGuard guard(c.device);
+    const size_t n = c.degree;
+    if (batch == 1) {
+        std::lock_guard<std::mutex> lock(c.staging_mutex);
+        LSR_HIP(hipMemcpyAsync(c.staging.ptr, polys, n * 8, hipMemcpyHostToDevice, c.stream));
+        launch_ntt(c, c.staging.ptr, 1, inverse, c.stream);
+        LSR_HIP(hipMemcpyAsync(polys, c.staging.ptr, n * 8, hipMemcpyDeviceToHost, c.stream));
+        LSR_HIP(hipStreamSynchronize(c.stream));
+        return;
+    }
+    const size_t chunk_polys = std::max<size_t>(1, std::min<size_t>(batch, (512ull << 20) / (n * 8)));
+    DeviceBuffer<uint64_t> buf(chunk_polys * n);
+    std::lock_guard<std::mutex> lock(c.staging_mutex);   // serialises use of c.stream
+    for (size_t done = 0; done < batch; done += chunk_polys) {
+        const size_t now = std::min(chunk_polys, batch - done);
+        LSR_HIP(hipMemcpyAsync(buf.ptr, polys + done * n, now * n * 8, hipMemcpyHostToDevice, c.stream));
+        launch_ntt(c, buf.ptr, now, inverse, c.stream);
+        LSR_HIP(hipMemcpyAsync(polys + done * n, buf.ptr, now * n * 8, hipMemcpyDeviceToHost, c.stream));
+        LSR_HIP(hipStreamSynchronize(c.stream));
+    }
+}
+
+static void host_pointwise(const NttContext& c, uint64_t* result, const uint64_t* a, const uint64_t* b, size_t count) {
+    if (!count) return;
+    DeviceGuard guard(c.device);
+    std::lock_guard<std::mutex> lock(c.staging_mutex);
+    DeviceBuffer<uint64_t> big;
+    uint64_t* base = c.staging.ptr;
+    if (3 * count > c.staging.count) {
+        big.allocate(3 * count);
+        base = big.ptr;
+    }
+    uint64_t* da = base;
+    uint64_t* db = base + count;
+    uint64_t* dr = base + 2 * count;
+    LSR_HIP(hipMemcpyAsync(da, a, count * 8, hipMemcpyHostToDevice, c.stream));
+    LSR_HIP(hipMemcpyAsync(db, b, count * 8, hipMemcpyHostToDevice, c.stream));
+    launch_pointwise(c, dr, da, db, count, c.stream);
+    LSR_HIP(hipMemcpyAsync(result, dr, count * 8, hipMemcpyDeviceToHost, c.stream));
+    LSR_HIP(hipStreamSynchronize(c.stream));
+}
+
+}  // namespace lsr
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+using lsr::set_last_error;
+
+template <class F>
+static int guarded(const char* where, F&& body) noexcept {
+    try {
+        body();
+        return 0;
+    } catch (const std::exception& e) {
+        set_last_error(std::string(where) + ": " + e.what());
+        std::fprintf(stderr, "lambda_snark_core: %s failed: %s\n", where, e.what());
+        return -1;
+    } catch (...) {
+        set_last_error(std::string(where) + ": unknown exception");
+        return -1;
+    }
+}
+
+extern "C" {
+
+int lsr_device_count(void) noexcept { return lsr::visible_device_count(); }
+const char* lsr_last_error(void) noexcept { return lsr::last_error_cstr(); }
+const char* lsr_version(void) noexcept { return "lambda_snark_core hip gfx950 r1 (f64-FMA Barrett + u64 Shoup NTT)"; }
+void lsr_set_arith_mode(int mode) noexcept { lsr::g_arith_mode.store(mode); }
+
+NttContext* ntt_context_create(uint64_t q, uint32_t n) noexcept {
+    try {
+        return lsr::create_ntt_context(q, n, -1);
+    } catch (...) {
+        return nullptr;
+    }
+}
+NttContext* lsr_ntt_context_create_on(uint64_t q, uint32_t n, int device) noexcept {
+    try {
+        return lsr::create_ntt_context(q, n, device);
+    } catch (...) {
+        return nullptr;
+    }
+}
+void ntt_context_free(NttContext* ctx) noexcept { lsr::destroy_ntt_context(ctx); }
+int lsr_ntt_context_device(const NttContext* ctx) noexcept { return ctx ? ctx->device : -1; }
+uint64_t lsr_ntt_context_root(const NttContext* ctx) noexcept { return ctx ? ctx->psi : 0; }
+int lsr_ntt_context_uses_f64(const NttContext* ctx) noexcept { return ctx && ctx->use_f64 ? 1 : 0; }
+
+int ntt_forward(const NttContext* ctx, uint64_t* coeffs, uint32_t n) noexcept {
+    if (!ctx || !coeffs || n != ctx->degree) return -1;   // ntt.cpp:81
+    return guarded("ntt_forward", [&] { lsr::host_ntt(*ctx, coeffs, 1, false); });
+}
+int ntt_inverse(const NttContext* ctx, uint64_t* evals, uint32_t n) noexcept {
+    if (!ctx || !evals || n != ctx->degree) return -1;    // ntt.cpp:96
+    return guarded("ntt_inverse", [&] { lsr::host_ntt(*ctx, evals, 1, true); });
+}
+void ntt_mul_pointwise(const NttContext* ctx, uint64_t* result, const uint64_t* a, const uint64_t* b, uint32_t n) noexcept {
+    if (!ctx || !result || !a || !b) return;              // ntt.cpp:113
+    (void)guarded("ntt_mul_pointwise", [&] { lsr::host_pointwise(*ctx, result, a, b, n); });
+}
+
+int ntt_forward_batch(const NttContext* ctx, uint64_t* polys, size_t batch) noexcept {
+    if (!ctx || !polys) return -1;
+    if (batch == 0) return 0;
+    return guarded("ntt_forward_batch", [&] { lsr::host_ntt(*ctx, polys, batch, false); });
+}
+int ntt_inverse_batch(const NttContext* ctx, uint64_t* polys, size_t batch) noexcept {
+    if (!ctx || !polys) return -1;
+    if (batch == 0) return 0;
+    return guarded("ntt_inverse_batch", [&] { lsr::host_ntt(*ctx, polys, batch, true); });
+}
+int ntt_mul_pointwise_batch(const NttContext* ctx, uint64_t* result, const uint64_t* a, const uint64_t* b, size_t batch) noexcept {
+    if (!ctx || !result || !a || !b) return -1;
+    return guarded("ntt_mul_pointwise_batch", [&] { lsr::host_pointwise(*ctx, result, a, b, batch * ctx->degree); });
+}
+
+int lsr_ntt_forward_batch_device(const NttContext* ctx, uint64_t* d_polys, size_t batch, void* stream) noexcept {
+    if (!ctx || !d_polys) return -1;
+    return guarded("lsr_ntt_forward_batch_device", [&] {
+        lsr::DeviceGuard guard(ctx->device);
+        lsr::launch_ntt(*ctx, d_polys, batch, false, static_cast<hipStream_t>(stream));
+    });
+}
+int lsr_ntt_inverse_batch_device(const NttContext* ctx, uint64_t* d_polys, size_t batch, void* stream) noexcept {
+    if (!ctx || !d_polys) return -1;
+    return guarded("lsr_ntt_inverse_batch_device", [&] {
+        lsr::DeviceGuard guard(ctx->device);
+        lsr::launch_ntt(*ctx, d_polys, batch, true, static_cast<hipStream_t>(stream));
+    });
+}
+int lsr_ntt_mul_pointwise_device(const NttContext* ctx, uint64_t* d_result, const uint64_t* d_a, const uint64_t* d_b, size_t count,
+                                 void* stream) noexcept {
+    if (!ctx || !d_result || !d_a || !d_b) return -1;
+    return guarded("lsr_ntt_mul_pointwise_device", [&] {
+        lsr::DeviceGuard guard(ctx->device);
+        lsr::launch_pointwise(*ctx, d_result, d_a, d_b, count, static_cast<hipStream_t>(stream));
+    });
+}
+
+uint64_t lsr_minimal_primitive_root(uint64_t q, uint32_t n) noexcept {
+    int logn = 0;
+    if (!lsr::ntt_params_valid(q, n, &logn)) return 0;
+    return lsr::minimal_primitive_root_2n(q, n);
+}
+uint64_t lsr_select_commit_modulus(uint64_t requested_q, uint32_t n) noexcept { return lsr::select_commit_modulus(requested_q, n); }
+uint64_t lsr_plain_modulus(uint32_t n) noexcept { return lsr::plain_modulus_for(n); }
+size_t lsr_gaussian_cdf(double sigma, uint64_t* cdf, size_t cap) noexcept {
+    try {
+        const std::vector<uint64_t> table = lsr::gaussian_cdf(sigma);
+        if (table.empty() || table.size() > cap || !cdf) return 0;
+        std::memcpy(cdf, table.data(), table.size() * sizeof(uint64_t));
+        return table.size();
+    } catch (...) {
+        return 0;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Host runtime shared by the C-ABI translation units: error reporting, device guards, contexts.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lsr_arith.hpp"
+#include "lsr_host_math.hpp"
+
+namespace lsr {
+
+void set_last_error(const std::string& msg);
+const char* last_error_cstr();
+
+struct HipFailure : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define LSR_HIP(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t lsr_e_ = (expr);                                                                           \
+        if (lsr_e_ != hipSuccess)                                                                             \
+            throw ::lsr::HipFailure(std::string(#expr) + ": " + hipGetErrorString(lsr_e_));                  \
+    } while (0)
+
+// Device selection that does not leak into the caller's thread state (Rust wrappers are Send, not
+// Sync: the calling thread may change between calls — SURVEY.md §8(b) "Threading").
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int device);
+    ~DeviceGuard();
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+
+private:
+    int previous_ = -1;
+    bool switched_ = false;
+};
+
+int default_device();          // LAMBDA_SNARK_DEVICE, else LOCAL_RANK (mod device count), else 0
+int visible_device_count();    // 0 if the runtime cannot see a GPU
+
+template <class T>
+struct DeviceBuffer {
+    T* ptr = nullptr;
+    size_t count = 0;
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t n) { allocate(n); }
+    ~DeviceBuffer() { release(); }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    void allocate(size_t n) {
+        release();
+        if (n) LSR_HIP(hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)));
+        count = n;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    void upload(const std::vector<T>& host) {
+        allocate(host.size());
+        if (!host.empty()) LSR_HIP(hipMemcpy(ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+}  // namespace lsr
+
+// The opaque C-ABI handle (reference: struct NttContext, cpp-core/src/ntt.cpp:21-26).
+struct NttContext {
+    uint64_t modulus = 0;
+    uint32_t degree = 0;
+    int logn = 0;
+    int device = 0;
+    bool use_f64 = false;
+    uint64_t psi = 0;
+    lsr::ModParams mod{};
+    // stage-order twiddles on the device; only the flavour in use is populated
+    lsr::DeviceBuffer<double> fwd_f64, inv_f64;
+    lsr::DeviceBuffer<lsr::ShoupOperand> fwd_u64, inv_u64;
+    double n_inv_f64 = 0, w_last_scaled_f64 = 0;
+    lsr::ShoupOperand n_inv_u64{}, w_last_scaled_u64{};
+    // staging for the single-polynomial host-pointer entry points
+    mutable std::mutex staging_mutex;
+    mutable lsr::DeviceBuffer<uint64_t> staging;   // 3 n words
+    hipStream_t stream = nullptr;
+};
+
+namespace lsr {
+
+NttContext* create_ntt_context(uint64_t q, uint32_t n, int device);
+void destroy_ntt_context(NttContext* ctx);
+// asynchronous launches on `stream`, data resident on ctx->device
+void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inverse, hipStream_t stream);
+void launch_pointwise(const NttContext& ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t count,
+                      hipStream_t stream);
+int arith_mode();
+
+}  // namespace lsr
