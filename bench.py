@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE config 2 — batched forward+inverse negacyclic NTT, n = 2^16, 4096 polynomials per
+GPU, device-resident, q16 = 17592182243329 (the 44-bit prime 17592169062401 of the reference cannot host
+n = 2^16: SURVEY.md F5) — plus config 3 (rank-4 Module-LWE matrix–vector commitment, 1024 witness vectors).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one forward pass + one inverse pass over the rank's 4096 polynomials (8192 transforms).  Ranks are
+independent (weak scaling, no data-path collective — SURVEY.md §8(e)); the only communication is the barrier and
+the MAX-reduction of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+Q16 = 17592182243329
+N = 65536
+NTT_BYTES = 2 * N * 8                 # algorithmic bytes of one transform: read n*8 + write n*8
+HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--polys", type=int, default=4096, help="polynomials per GPU (config 2: 4096)")
+    ap.add_argument("--commits", type=int, default=1024, help="witness vectors per GPU (config 3: 1024)")
+    ap.add_argument("--rank", type=int, default=4, help="module rank k of the commitment workload")
+    ap.add_argument("--no-commit", action="store_true", help="skip the config-3 section")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-polys", type=int, default=2048, help="CPU baseline sample: polynomials transformed fwd+inv on one core")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_polys):
+    """The oracle (a restatement of the SEAL Harvey NTT the reference calls) timed on ONE host core — the
+    reference's execution model is single-threaded.  kind = "port": the reference itself cannot be
+    built here (SEAL absent)."""
+    import __graft_entry__ as entry
+    orc = entry.load_oracle()
+    h = orc.ntt_handle(Q16, N)
+    chunk = 64
+    buf = orc.splitmix(0xDEADBEEF, Q16, chunk * N)
+    done = 0
+    t0 = time.perf_counter()
+    while done < sample_polys:
+        orc.L.oracle_ntt_forward_batch(h, buf.ctypes.data, chunk)
+        orc.L.oracle_ntt_inverse_batch(h, buf.ctypes.data, chunk)
+        done += chunk
+    dt = time.perf_counter() - t0
+    return {"value": 2 * done / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
+            "sample": f"{done} polys x (fwd+inv), n=2^16, q={Q16}, single thread, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU; the library has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    pkg = entry.load_package()
+    ctx = pkg.NttContext(Q16, N, device=local)
+    stream = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0xDEADBEEF + rank)
+    polys = torch.randint(0, Q16, (args.polys, N), dtype=torch.int64, device="cuda", generator=gen)
+    reference_copy = polys[:8].clone()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        ctx.forward_device(polys.data_ptr(), args.polys, stream)
+        ctx.inverse_device(polys.data_ptr(), args.polys, stream)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    verified = bool(torch.equal(polys[:8], reference_copy))        # fwd∘inv identity survived every step
+
+    # per-direction device time with HIP events on the launch stream (roofline figure)
+    def event_time(fn, reps):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e-3
+
+    reps = max(5, min(args.steps, 20))
+    t_fwd = event_time(lambda: ctx.forward_device(polys.data_ptr(), args.polys, stream), reps)
+    t_inv = event_time(lambda: ctx.inverse_device(polys.data_ptr(), args.polys, stream), reps)
+    fwd_rate, inv_rate = args.polys / t_fwd, args.polys / t_inv
+
+    extra = {"fwd_ntt_per_s": fwd_rate, "inv_ntt_per_s": inv_rate, "fwd_ms_per_batch": t_fwd * 1e3, "inv_ms_per_batch": t_inv * 1e3,
+             "verified_roundtrip": verified, "arith": "f64-FMA Barrett" if ctx.uses_f64 else "u64 Shoup"}
+
+    # ---- config 3: rank-k Module-LWE matrix–vector commitment u = INTT(A^T NTT(r)) + e1 ----
+    if not args.no_commit:
+        del polys
+        torch.cuda.empty_cache()
+        k = args.rank
+        lctx = pkg.LweContext(pkg.Params(q=Q16, n=N, k=k, sigma=3.19), key_seed=0xC0DE + 1, device=local)
+        r = torch.randint(0, Q16, (args.commits, k, N), dtype=torch.int64, device="cuda", generator=gen)
+        e1 = torch.randint(0, 8, (args.commits, k, N), dtype=torch.int64, device="cuda", generator=gen)   # stand-in blinding residues for timing
+        u = torch.empty_like(r)
+        lib = pkg._abi.lib()
+
+        def commit_step():
+            # the API leaves NTT(r) in r: the next step's witness vectors are those (still uniform residues in [0,q))
+            rc = lib.lsr_mlwe_matvec_batch_device(lctx.handle, r.data_ptr(), e1.data_ptr(), u.data_ptr(), args.commits, None, stream)
+            assert rc == 0
+
+        for _ in range(max(1, args.warmup // 2)):
+            commit_step()
+        barrier()
+        c0 = time.perf_counter()
+        csteps = max(3, args.steps // 2)
+        for _ in range(csteps):
+            commit_step()
+        barrier()
+        c_el = time.perf_counter() - c0
+        if world > 1:
+            t = torch.tensor([c_el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c_el = float(t.item())
+        commit_bytes = 3 * k * N * 8      # read r + read e1 + write u (6 291 456 B at k = 4)
+        commits_per_s = world * args.commits * csteps / c_el
+        extra.update({"commits_per_s": commits_per_s, "commit_rank": k, "commits_per_gpu": args.commits,
+                      "commit_roofline_frac": commits_per_s / world * commit_bytes / (HBM_PEAK_GBS * 1e9)})
+        lctx.close()
+
+    if rank == 0:
+        transforms = 2 * args.polys * args.steps * world
+        value = transforms / elapsed
+        achieved = fwd_rate * NTT_BYTES / 1e9
+        line = {
+            "metric": "degree-2^16 NTTs/sec (forward+inverse, batched, device-resident)",
+            "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 residues (exact f64-FMA Barrett arithmetic)" if ctx.uses_f64 else "u64", "data": "synthetic",
+            "config": {"workload": "config2: batched forward+inverse negacyclic NTT, n=2^16, 4096 polys/GPU, q=17592182243329 (44-bit)",
+                       "polys_per_gpu": args.polys, "ring_degree": N, "modulus": Q16, "parallelism": f"independent batches x{world}, no collectives"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "forward NTT batch (strided round + tile kernel), 1 MiB algorithmic bytes per transform"},
+            "extra": extra,
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_polys)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

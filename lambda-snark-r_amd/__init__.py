@@ -1,0 +1,273 @@
+"""Host-side mirror of the reference's safe wrappers over the lambda-snark-sys C-ABI.
+
+The reference's host language is Rust (absent from this image), so the wrappers that sit above the
+C-ABI are mirrored here in Python with the same names, argument meaning and error behaviour:
+
+* ``LweContext``  <-> rust-api/lambda-snark/src/context.rs:14-76   (``LweContext::new`` -> ``lwe_context_create``)
+* ``Commitment``  <-> rust-api/lambda-snark/src/commitment.rs:31-121 (``new``, ``clone``, ``linear_combine``, ``as_bytes``)
+* ``verify_opening_with_context`` <-> rust-api/lambda-snark/src/opening.rs:160-222
+* ``NttContext``  <-> the ``ntt_*`` symbols (only exercised by cpp-core/tests/test_ntt.cpp in the reference)
+
+All arithmetic happens in liblambda_snark_core.so (HIP, gfx950).  Nothing here computes; there is no
+CPU fallback.  (The directory name has a hyphen; load it through ``__graft_entry__.load_package()``.)
+"""
+import ctypes
+
+import numpy as np
+
+from . import _abi
+from ._abi import PROFILE_RING_B, PROFILE_SCALAR_A, LweCommitment, LweOpening, PublicParams
+
+__all__ = [
+    "NttContext", "LweContext", "Commitment", "Params", "CoreError", "verify_opening_with_context",
+    "sample_gaussian", "PublicParams", "PROFILE_RING_B", "PROFILE_SCALAR_A",
+]
+
+
+class CoreError(RuntimeError):
+    """Mirror of lambda_snark_core::Error::{FfiError, CommitmentFailed, InvalidDimensions}."""
+
+
+def _u64_array(values, name="array"):
+    arr = np.ascontiguousarray(values, dtype=np.uint64)
+    if arr.ndim == 0:
+        raise ValueError(f"{name} must be an array")
+    return arr
+
+
+class NttContext:
+    """RAII handle over ``NttContext*`` (cpp-core/include/lambda_snark/ntt.h:25-41)."""
+
+    def __init__(self, q, n, device=-1):
+        self._lib = _abi.lib()
+        self.q, self.n = int(q), int(n)
+        self._h = self._lib.lsr_ntt_context_create_on(self.q, self.n, device) if device >= 0 else self._lib.ntt_context_create(self.q, self.n)
+        if not self._h:
+            raise CoreError(f"ntt_context_create({q}, {n}) returned NULL: {_abi.last_error()}")
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def root(self):
+        return self._lib.lsr_ntt_context_root(self._h)
+
+    @property
+    def uses_f64(self):
+        return bool(self._lib.lsr_ntt_context_uses_f64(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ntt_context_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # --- reference single-polynomial entry points (host buffers, in place) ---
+    def forward(self, coeffs):
+        a = _u64_array(coeffs).copy()
+        if self._lib.ntt_forward(self._h, a.ctypes.data, a.size) != 0:
+            raise CoreError("ntt_forward failed")
+        return a
+
+    def inverse(self, evals):
+        a = _u64_array(evals).copy()
+        if self._lib.ntt_inverse(self._h, a.ctypes.data, a.size) != 0:
+            raise CoreError("ntt_inverse failed")
+        return a
+
+    def mul_pointwise(self, a, b):
+        a, b = _u64_array(a), _u64_array(b)
+        out = np.zeros_like(a)
+        self._lib.ntt_mul_pointwise(self._h, out.ctypes.data, a.ctypes.data, b.ctypes.data, a.size)
+        return out
+
+    # --- batched host entry points ([batch][n]) ---
+    def forward_batch(self, polys):
+        a = _u64_array(polys).copy().reshape(-1, self.n)
+        if self._lib.ntt_forward_batch(self._h, a.ctypes.data, a.shape[0]) != 0:
+            raise CoreError("ntt_forward_batch failed: " + _abi.last_error())
+        return a
+
+    def inverse_batch(self, polys):
+        a = _u64_array(polys).copy().reshape(-1, self.n)
+        if self._lib.ntt_inverse_batch(self._h, a.ctypes.data, a.shape[0]) != 0:
+            raise CoreError("ntt_inverse_batch failed: " + _abi.last_error())
+        return a
+
+    # --- device-resident entry points (raw device pointers, e.g. torch.Tensor.data_ptr()) ---
+    def forward_device(self, dptr, batch, stream=0):
+        if self._lib.lsr_ntt_forward_batch_device(self._h, dptr, batch, stream) != 0:
+            raise CoreError("lsr_ntt_forward_batch_device failed: " + _abi.last_error())
+
+    def inverse_device(self, dptr, batch, stream=0):
+        if self._lib.lsr_ntt_inverse_batch_device(self._h, dptr, batch, stream) != 0:
+            raise CoreError("lsr_ntt_inverse_batch_device failed: " + _abi.last_error())
+
+    def mul_pointwise_device(self, dres, da, db, count, stream=0):
+        if self._lib.lsr_ntt_mul_pointwise_device(self._h, dres, da, db, count, stream) != 0:
+            raise CoreError("lsr_ntt_mul_pointwise_device failed: " + _abi.last_error())
+
+
+class Params:
+    """Mirror of lambda_snark_core::Params (rust-api/lambda-snark-core/src/lib.rs:136-196), RingB profile."""
+
+    def __init__(self, security_level=128, q=17592186044417, n=4096, k=2, sigma=3.19, profile=PROFILE_RING_B):
+        self.security_level, self.q, self.n, self.k, self.sigma, self.profile = security_level, q, n, k, sigma, profile
+
+    def to_ffi(self):
+        # context.rs:18-42: ScalarA is sent as ring_degree = 1, module_rank = 1
+        if self.profile == PROFILE_SCALAR_A:
+            return PublicParams(PROFILE_SCALAR_A, self.security_level, self.q, 1, 1, self.sigma)
+        return PublicParams(PROFILE_RING_B, self.security_level, self.q, self.n, self.k, self.sigma)
+
+
+class LweContext:
+    """Mirror of lambda_snark::LweContext (context.rs:14-76)."""
+
+    def __init__(self, params, key_seed=None, device=-1):
+        self._lib = _abi.lib()
+        self.params = params
+        ffi = params.to_ffi()
+        if key_seed is None and device < 0:
+            self._h = self._lib.lwe_context_create(ctypes.byref(ffi))
+        else:
+            self._h = self._lib.lsr_lwe_context_create_seeded(ctypes.byref(ffi), int(key_seed or 0), device)
+        if not self._h:
+            raise CoreError("FfiError: lwe_context_create returned NULL")   # context.rs:46-48
+
+    @property
+    def handle(self):
+        return self._h
+
+    def modulus(self):
+        """context.rs:90 returns params.q; the ring modulus actually used is ``commit_modulus``."""
+        return self.params.q
+
+    @property
+    def commit_modulus(self):
+        return self._lib.lsr_lwe_modulus(self._h)
+
+    @property
+    def plain_modulus(self):
+        return self._lib.lsr_lwe_plain_modulus(self._h)
+
+    @property
+    def ring_degree(self):
+        return self._lib.lsr_lwe_ring_degree(self._h)
+
+    @property
+    def module_rank(self):
+        return self._lib.lsr_lwe_module_rank(self._h)
+
+    def public_matrix(self):
+        k, n = self.module_rank, self.ring_degree
+        a = np.zeros((k, k, n), dtype=np.uint64)
+        if self._lib.lsr_lwe_public_matrix(self._h, a.ctypes.data) != 0:
+            raise CoreError("lsr_lwe_public_matrix failed")
+        return a
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lwe_context_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class Commitment:
+    """Mirror of lambda_snark::Commitment (commitment.rs:31-121)."""
+
+    def __init__(self, ctx, message=None, seed=0, _raw=None):
+        self._lib = _abi.lib()
+        self._ctx = ctx
+        if _raw is not None:
+            self._p = _raw
+            return
+        # commitment.rs:33-36: every coefficient is reduced mod ctx.modulus() before the call
+        msg = np.array([int(m) % ctx.modulus() for m in message], dtype=np.uint64)
+        self._p = self._lib.lwe_commit(ctx.handle, msg.ctypes.data, msg.size, int(seed))
+        if not self._p:
+            raise CoreError("CommitmentFailed")   # commitment.rs:40-42
+
+    @classmethod
+    def batch(cls, ctx, messages, seeds):
+        """``lwe_commit_batch``: messages [batch][msg_len], seeds [batch]."""
+        lib = _abi.lib()
+        msgs = np.ascontiguousarray(messages, dtype=np.uint64)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        out = (ctypes.POINTER(LweCommitment) * msgs.shape[0])()
+        if lib.lwe_commit_batch(ctx.handle, msgs.ctypes.data, msgs.shape[1], msgs.shape[0], seeds.ctypes.data, out) != 0:
+            raise CoreError("CommitmentFailed: " + _abi.last_error())
+        return [cls(ctx, _raw=out[i]) for i in range(msgs.shape[0])]
+
+    def clone(self):
+        p = self._lib.lwe_commitment_clone(self._p)
+        if not p:
+            raise CoreError("lwe_commitment_clone returned NULL")   # commitment.rs:22-24 panics
+        return Commitment(self._ctx, _raw=p)
+
+    @staticmethod
+    def linear_combine(ctx, commitments, coeffs):
+        """commitment.rs:60-84 (coefficients reduced mod ctx.modulus() first, :66-69)."""
+        if len(commitments) == 0:
+            raise ValueError("no commitments provided")                     # commitment.rs:66-68
+        if len(commitments) != len(coeffs):
+            raise ValueError("commitments/coeffs length mismatch")          # commitment.rs:70-74
+        lib = _abi.lib()
+        arr = (ctypes.POINTER(LweCommitment) * len(commitments))(*[c._p if c is not None else None for c in commitments])
+        cf = np.array([int(c) % ctx.modulus() for c in coeffs], dtype=np.uint64)
+        p = lib.lwe_linear_combine(ctx.handle, arr, cf.ctypes.data, len(commitments))
+        if not p:
+            raise CoreError("CommitmentFailed")   # commitment.rs:80-82
+        return Commitment(ctx, _raw=p)
+
+    def as_words(self):
+        """commitment.rs:88-93: the flat u64 words (hashed word-by-word by the Fiat–Shamir transcript)."""
+        c = self._p.contents
+        return np.ctypeslib.as_array(c.data, shape=(c.len,)).copy()
+
+    def as_bytes(self):
+        return self.as_words().tobytes()
+
+    def __len__(self):
+        return self._p.contents.len
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self._lib.lwe_commitment_free(self._p)
+            self._p = None
+
+    __del__ = free
+
+
+def verify_opening_with_context(ctx, commitment, message, randomness=None):
+    """opening.rs:160-222 -> ``lwe_verify_opening``; returns True/False, raises on -1."""
+    lib = _abi.lib()
+    msg = np.array([int(m) % ctx.modulus() for m in message], dtype=np.uint64)   # opening.rs:198-201
+    rnd = np.zeros(1, dtype=np.uint64) if randomness is None else _u64_array(randomness)
+    opening = LweOpening(rnd.ctypes.data_as(_abi.u64p), rnd.size)
+    rc = lib.lwe_verify_opening(ctx.handle, commitment._p, msg.ctypes.data, msg.size, ctypes.byref(opening))
+    if rc < 0:
+        raise CoreError("lwe_verify_opening returned -1")
+    return rc == 1
+
+
+def sample_gaussian(length, sigma, seed=None, domain=16, index=0):
+    """``sample_gaussian`` (utils.h:27) or its seeded twin; returns int64 samples."""
+    lib = _abi.lib()
+    out = np.zeros(length, dtype=np.uint64)
+    if seed is None:
+        rc = lib.sample_gaussian(out.ctypes.data, length, float(sigma))
+    else:
+        rc = lib.lsr_sample_gaussian_seeded(out.ctypes.data, length, float(sigma), int(seed), int(domain), int(index))
+    if rc != 0:
+        raise CoreError("sample_gaussian failed")
+    return out.view(np.int64)

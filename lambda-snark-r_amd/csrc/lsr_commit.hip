@@ -1,0 +1,578 @@
+// Module-LWE commitment on the GPU and the lwe_* C-ABI (reference: cpp-core/src/commitment.cpp).
+//
+// Scheme (DESIGN.md "Commitment definition"; satisfies the documented contract of
+// cpp-core/include/lambda_snark/commitment.h:43-52, which the SEAL-backed reference does not implement):
+//   context : A_hat in R_q^{k x k} uniform (NTT domain), s, e <- chi^k, b_hat = A_hat s_hat + e_hat,
+//             t = SEAL Batching(n,20) prime, Delta = floor(q/t)
+//   commit  : r, e1 <- chi^k, e2 <- chi (ChaCha20 stream of `seed`)
+//             u = INTT(A_hat^T r_hat) + e1                 (the matrix–vector + blinding-add workload)
+//             v = INTT(<b_hat, r_hat>) + e2 + Delta (m mod t)
+//   verify  : round(t/q (v - <s,u>)) mod t == m mod t       (trapdoor check, as the reference decrypts)
+//   combine : sum_i (c_i mod t) (u_i, v_i)
+// Wire format: data[0] = payload bytes; payload = {"LSRC0001", n | k<<32, q, t, u[k][n], v[n]}.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "lambda_snark/batch.h"
+#include "lambda_snark/commitment.h"
+#include "lsr_arith.hpp"
+#include "lsr_runtime.hpp"
+#include "lsr_sampler.hpp"
+
+namespace lsr {
+
+constexpr uint64_t kWireMagic = 0x313030304352534CULL;   // "LSRC0001"
+constexpr size_t kHeaderWords = 5;                        // data[0] + 4 header words
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+// out[j][row][x] = sum_col M[row*row_stride + col*col_stride][x] * vec[j][col][x]  (+ add[row][x])   mod q
+// One lane per (j, row, x).  F64 selects the exact FP64-FMA product (q < 2^45).
+template <bool F64>
+__global__ void __launch_bounds__(256) matvec_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ mat, const uint64_t* __restrict__ vec,
+                                                       const uint64_t* __restrict__ add, uint32_t rows, uint32_t cols, uint32_t row_stride,
+                                                       uint32_t col_stride, uint32_t logn, uint64_t batch, ModParams p) {
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t n = 1ull << logn;
+    if (gid >= batch * rows * n) return;
+    const uint64_t x = gid & (n - 1);
+    const uint64_t jr = gid >> logn;
+    const uint64_t row = jr % rows;
+    const uint64_t j = jr / rows;
+    const uint64_t* v = vec + (j * cols) * n + x;
+    const uint64_t* m = mat + (row * row_stride) * n + x;
+    uint64_t result;
+    if (F64) {
+        double acc = add ? f64_from_u52(add[row * n + x]) : 0.0;
+        for (uint32_t c = 0; c < cols; ++c)
+            acc += mulmod_f64(f64_from_u52(m[(uint64_t)c * col_stride * n]), f64_from_u52(v[(uint64_t)c * n]), p.qd, p.inv_qd);
+        result = u52_from_f64(canonical_f64(acc, p.qd, p.inv_qd));
+    } else {
+        uint64_t acc = add ? add[row * n + x] : 0;
+        for (uint32_t c = 0; c < cols; ++c) {
+            acc += mulmod_barrett128(m[(uint64_t)c * col_stride * n], v[(uint64_t)c * n], p);
+            if (acc >= p.q) acc -= p.q;
+        }
+        result = acc;
+    }
+    out[gid] = result;
+}
+
+// dst = (dst + a (+ b)) mod q, all canonical
+__global__ void __launch_bounds__(256) add_mod_kernel(uint64_t* __restrict__ dst, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
+                                                        uint64_t count, uint64_t q) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        uint64_t s = dst[i] + a[i];
+        if (s >= q) s -= q;
+        if (b) {
+            s += b[i];
+            if (s >= q) s -= q;
+        }
+        dst[i] = s;
+    }
+}
+
+// acc = (acc + c * x) mod q
+__global__ void __launch_bounds__(256) axpy_mod_kernel(uint64_t* __restrict__ acc, const uint64_t* __restrict__ x, uint64_t c, uint64_t count, ModParams p) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        uint64_t s = acc[i] + mulmod_barrett128(c, x[i], p);
+        if (s >= p.q) s -= p.q;
+        acc[i] = s;
+    }
+}
+
+// w = v_hat - <s_hat, u_hat> is computed with matvec (rows = 1) and a subtraction; this kernel does
+// dst = (a - dst) mod q
+__global__ void __launch_bounds__(256) rsub_mod_kernel(uint64_t* __restrict__ dst, const uint64_t* __restrict__ a, uint64_t count, uint64_t q) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const uint64_t d = dst[i], s = a[i];
+        dst[i] = s >= d ? s - d : s + q - d;
+    }
+}
+
+// floor((hi:lo) / q) for a dividend below 2^61 * 2^21 (quotient fits 64 bits), by Barrett + fix-up
+__device__ __forceinline__ uint64_t div128_by_q(uint64_t hi, uint64_t lo, const ModParams& p) {
+    const uint64_t c1 = __umul64hi(lo, p.barrett_lo);
+    const uint64_t m1_lo = lo * p.barrett_hi, m1_hi = __umul64hi(lo, p.barrett_hi);
+    const uint64_t m2_lo = hi * p.barrett_lo, m2_hi = __umul64hi(hi, p.barrett_lo);
+    uint64_t s = c1 + m1_lo;
+    uint64_t carry = s < c1;
+    const uint64_t s2 = s + m2_lo;
+    carry += s2 < s;
+    uint64_t quot = hi * p.barrett_hi + m1_hi + m2_hi + carry;
+    uint64_t rem = lo - quot * p.q;
+    while (rem >= p.q) { rem -= p.q; ++quot; }
+    return quot;
+}
+
+// flag |= OR_i ( round(t * w_i / q) mod t ) xor (msg_i mod t)   — OR-of-XOR compare of commitment.cpp:223-228
+__global__ void __launch_bounds__(256) decode_compare_kernel(const uint64_t* __restrict__ w, const uint64_t* __restrict__ msg, uint64_t msg_len,
+                                                               uint64_t t, ModParams p, unsigned long long* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t diff = 0;
+    if (i < msg_len) {
+        const uint64_t lo0 = w[i] * t, hi0 = __umul64hi(w[i], t);
+        const uint64_t lo = lo0 + (p.q >> 1);
+        const uint64_t hi = hi0 + (lo < lo0);
+        const uint64_t decoded = div128_by_q(hi, lo, p) % t;
+        diff = decoded ^ (msg[i] % t);
+    }
+    if (diff) atomicOr(flag, (unsigned long long)diff);
+}
+
+static unsigned grid_for(uint64_t work, unsigned cap = 256 * 16) {
+    const uint64_t blocks = (work + 255) / 256;
+    return static_cast<unsigned>(std::min<uint64_t>(blocks, cap));
+}
+
+}  // namespace lsr
+
+// ------------------------------------------------------------------------------------------------
+// the opaque context (reference: struct LweContext, commitment.cpp:31-40)
+// ------------------------------------------------------------------------------------------------
+struct LweContext {
+    PublicParams params{};
+    uint64_t q = 0, t = 0, delta = 0;
+    uint32_t n = 0, k = 0;
+    int logn = 0;
+    double sigma = 0;
+    int device = 0;
+    NttContext* ntt = nullptr;
+    lsr::DeviceBuffer<uint64_t> a_hat, s_hat, b_hat, cdf;
+    uint32_t cdf_entries = 0;
+    // scratch for commit / verify / combine, grown on demand; guarded by `mutex`
+    mutable std::mutex mutex;
+    mutable lsr::DeviceBuffer<uint64_t> ws_r, ws_e1, ws_e2, ws_u, ws_v, ws_dm, ws_seeds;
+    mutable lsr::DeviceBuffer<unsigned long long> ws_flag;
+    mutable size_t ws_batch = 0;
+};
+
+namespace lsr {
+
+static void matvec(const LweContext& c, uint64_t* out, const uint64_t* mat, const uint64_t* vec, const uint64_t* add, uint32_t rows, uint32_t cols,
+                   uint32_t row_stride, uint32_t col_stride, uint64_t batch, hipStream_t s) {
+    const uint64_t work = batch * rows * (uint64_t)c.n;
+    if (!work) return;
+    const unsigned grid = static_cast<unsigned>((work + 255) / 256);
+    if (c.ntt->use_f64)
+        hipLaunchKernelGGL(matvec_kernel<true>, dim3(grid), dim3(256), 0, s, out, mat, vec, add, rows, cols, row_stride, col_stride, (uint32_t)c.logn, batch, c.ntt->mod);
+    else
+        hipLaunchKernelGGL(matvec_kernel<false>, dim3(grid), dim3(256), 0, s, out, mat, vec, add, rows, cols, row_stride, col_stride, (uint32_t)c.logn, batch, c.ntt->mod);
+    LSR_HIP(hipGetLastError());
+}
+
+static void ensure_workspace(const LweContext& c, size_t batch) {
+    if (batch <= c.ws_batch) return;
+    const size_t kn = (size_t)c.k * c.n;
+    c.ws_r.allocate(batch * kn);
+    c.ws_e1.allocate(batch * kn);
+    c.ws_u.allocate(batch * kn);
+    c.ws_e2.allocate(batch * c.n);
+    c.ws_v.allocate(batch * c.n);
+    c.ws_dm.allocate(batch * c.n);
+    c.ws_seeds.allocate(batch);
+    if (!c.ws_flag.ptr) c.ws_flag.allocate(1);
+    c.ws_batch = batch;
+}
+
+static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_seed, int device) {
+    if (!params) return nullptr;                                   // commitment.cpp:103
+    uint32_t k = params->module_rank ? params->module_rank : 1;
+    const uint32_t n = params->ring_degree;
+    if (k > 16 || !(params->sigma > 0.0) || !std::isfinite(params->sigma) || params->sigma > 256.0) {
+        set_last_error("lwe_context_create: module_rank must be <= 16 and sigma finite in (0, 256]");
+        std::fprintf(stderr, "lwe_context_create error: unsupported module_rank / sigma\n");
+        return nullptr;
+    }
+    const uint64_t q = select_commit_modulus(params->modulus, n);
+    const uint64_t t = q ? plain_modulus_for(n) : 0;
+    if (!q || !t) {
+        set_last_error("lwe_context_create: ring_degree must be a power of two in [2, 131072]");
+        std::fprintf(stderr, "lwe_context_create error: unsupported ring_degree %u\n", n);
+        return nullptr;
+    }
+    std::unique_ptr<LweContext> c(new LweContext);
+    c->params = *params;
+    c->q = q; c->t = t; c->delta = q / t; c->n = n; c->k = k; c->sigma = params->sigma;
+    c->ntt = create_ntt_context(q, n, device);
+    if (!c->ntt) {
+        std::fprintf(stderr, "lwe_context_create error: %s\n", last_error_cstr());
+        return nullptr;
+    }
+    c->device = c->ntt->device;
+    c->logn = c->ntt->logn;
+    try {
+        DeviceGuard guard(c->device);
+        const std::vector<uint64_t> table = gaussian_cdf(c->sigma);
+        c->cdf.upload(table);
+        c->cdf_entries = static_cast<uint32_t>(table.size());
+        if (key_seed == 0) key_seed = os_entropy64() | 1ull;
+        const size_t kn = (size_t)k * n;
+        c->a_hat.allocate((size_t)k * kn);
+        c->s_hat.allocate(kn);
+        c->b_hat.allocate(kn);
+        DeviceBuffer<uint64_t> seed, e_hat(kn);
+        seed.upload(std::vector<uint64_t>{key_seed});
+        hipStream_t s = c->ntt->stream;
+        launch_uniform(c->a_hat.ptr, seed.ptr, 0, k * k, kDomA, n, (uint64_t)k * k, q, s);
+        launch_gaussian(GaussianJob{c->s_hat.ptr, seed.ptr, 0, k, kDomS, n, k, q}, c->cdf.ptr, c->cdf_entries, s);
+        launch_gaussian(GaussianJob{e_hat.ptr, seed.ptr, 0, k, kDomE, n, k, q}, c->cdf.ptr, c->cdf_entries, s);
+        launch_ntt(*c->ntt, c->s_hat.ptr, k, false, s);
+        launch_ntt(*c->ntt, e_hat.ptr, k, false, s);
+        // b_hat[i] = sum_j A_hat[i][j] s_hat[j] + e_hat[i]
+        matvec(*c, c->b_hat.ptr, c->a_hat.ptr, c->s_hat.ptr, e_hat.ptr, k, k, k, 1, 1, s);
+        LSR_HIP(hipStreamSynchronize(s));
+    } catch (const std::exception& e) {
+        set_last_error(std::string("lwe_context_create: ") + e.what());
+        std::fprintf(stderr, "lwe_context_create error: %s\n", e.what());
+        destroy_ntt_context(c->ntt);
+        return nullptr;
+    }
+    return c.release();
+}
+
+static void destroy_lwe_context(LweContext* c) {
+    if (!c) return;
+    try {
+        DeviceGuard guard(c->device);
+        if (c->s_hat.ptr) (void)hipMemset(c->s_hat.ptr, 0, c->s_hat.count * 8);   // zeroize the secret (commitment.h:34)
+        (void)hipDeviceSynchronize();
+        c->a_hat.release(); c->s_hat.release(); c->b_hat.release(); c->cdf.release();
+        c->ws_r.release(); c->ws_e1.release(); c->ws_e2.release(); c->ws_u.release(); c->ws_v.release();
+        c->ws_dm.release(); c->ws_seeds.release(); c->ws_flag.release();
+    } catch (...) {
+    }
+    destroy_ntt_context(c->ntt);
+    delete c;
+}
+
+// u = INTT(A_hat^T NTT(r)) + e1 on device-resident [batch][k][n] arrays (r is overwritten by NTT(r))
+static void mlwe_matvec_device(const LweContext& c, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s) {
+    const uint32_t k = c.k;
+    launch_ntt(*c.ntt, d_r, batch * k, false, s);
+    // u[j][col] = sum_i A_hat[i][col] r_hat[j][i]  -> "rows" = col, M[row*1 + i*k]
+    matvec(c, d_u, c.a_hat.ptr, d_r, nullptr, k, k, 1, k, batch, s);
+    launch_ntt(*c.ntt, d_u, batch * k, true, s);
+    if (d_e1) {
+        const uint64_t count = (uint64_t)batch * k * c.n;
+        hipLaunchKernelGGL(add_mod_kernel, dim3(grid_for(count)), dim3(256), 0, s, d_u, d_e1, (const uint64_t*)nullptr, count, c.q);
+        LSR_HIP(hipGetLastError());
+    }
+}
+
+static LweCommitment* new_commitment(size_t words) {
+    auto* out = new LweCommitment;
+    out->len = words;
+    out->data = new uint64_t[words];
+    return out;
+}
+
+static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, LweCommitment** out) {
+    const uint32_t n = c.n, k = c.k;
+    const size_t kn = (size_t)k * n;
+    ensure_workspace(c, batch);
+    hipStream_t s = c.ntt->stream;
+    // host prep: per-commit seeds (0 => fresh entropy, commitment.h:52) and Delta * (m mod t), truncated / zero-padded to n slots
+    std::vector<uint64_t> seed_host(batch), dm(batch * (size_t)n, 0);
+    const size_t copy = std::min<size_t>(msg_len, n);                       // commitment.cpp:146-149
+    for (size_t j = 0; j < batch; ++j) {
+        seed_host[j] = seeds && seeds[j] ? seeds[j] : (os_entropy64() | 1ull);
+        for (size_t x = 0; x < copy; ++x) dm[j * n + x] = c.delta * (messages[j * msg_len + x] % c.t);
+    }
+    LSR_HIP(hipMemcpyAsync(c.ws_seeds.ptr, seed_host.data(), batch * 8, hipMemcpyHostToDevice, s));
+    LSR_HIP(hipMemcpyAsync(c.ws_dm.ptr, dm.data(), dm.size() * 8, hipMemcpyHostToDevice, s));
+    launch_gaussian(GaussianJob{c.ws_r.ptr, c.ws_seeds.ptr, 0, k, kDomR, n, batch * k, c.q}, c.cdf.ptr, c.cdf_entries, s);
+    launch_gaussian(GaussianJob{c.ws_e1.ptr, c.ws_seeds.ptr, 0, k, kDomE1, n, batch * k, c.q}, c.cdf.ptr, c.cdf_entries, s);
+    launch_gaussian(GaussianJob{c.ws_e2.ptr, c.ws_seeds.ptr, 0, 1, kDomE2, n, batch, c.q}, c.cdf.ptr, c.cdf_entries, s);
+    mlwe_matvec_device(c, c.ws_r.ptr, c.ws_e1.ptr, c.ws_u.ptr, batch, s);    // leaves r_hat in ws_r
+    // v = INTT(<b_hat, r_hat>) + e2 + Delta m
+    matvec(c, c.ws_v.ptr, c.b_hat.ptr, c.ws_r.ptr, nullptr, 1, k, 0, 1, batch, s);
+    launch_ntt(*c.ntt, c.ws_v.ptr, batch, true, s);
+    const uint64_t vcount = (uint64_t)batch * n;
+    hipLaunchKernelGGL(add_mod_kernel, dim3(grid_for(vcount)), dim3(256), 0, s, c.ws_v.ptr, c.ws_e2.ptr, c.ws_dm.ptr, vcount, c.q);
+    LSR_HIP(hipGetLastError());
+    // gather
+    const size_t words = kHeaderWords + kn + n;
+    std::vector<LweCommitment*> made(batch, nullptr);
+    try {
+        for (size_t j = 0; j < batch; ++j) {
+            made[j] = new_commitment(words);
+            uint64_t* d = made[j]->data;
+            d[0] = 8ull * (words - 1);
+            d[1] = kWireMagic;
+            d[2] = (uint64_t)n | ((uint64_t)k << 32);
+            d[3] = c.q;
+            d[4] = c.t;
+            LSR_HIP(hipMemcpyAsync(d + kHeaderWords, c.ws_u.ptr + j * kn, kn * 8, hipMemcpyDeviceToHost, s));
+            LSR_HIP(hipMemcpyAsync(d + kHeaderWords + kn, c.ws_v.ptr + j * n, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        }
+        LSR_HIP(hipStreamSynchronize(s));
+    } catch (...) {
+        (void)hipStreamSynchronize(s);
+        for (LweCommitment* m : made) {
+            if (m) { delete[] m->data; delete m; }
+        }
+        throw;
+    }
+    for (size_t j = 0; j < batch; ++j) out[j] = made[j];
+}
+
+// parsed view of a commitment that belongs to this context, or false
+static bool parse_commitment(const LweContext& c, const LweCommitment* cm, const uint64_t** body) {
+    if (!cm || !cm->data || cm->len < 1) return false;
+    const uint64_t byte_len = cm->data[0];
+    if (byte_len == 0 || byte_len > (cm->len - 1) * 8) return false;       // commitment.cpp:71-75
+    const size_t words = kHeaderWords + (size_t)(c.k + 1) * c.n;
+    if (byte_len != 8ull * (words - 1)) return false;
+    const uint64_t* d = cm->data;
+    if (d[1] != kWireMagic || d[2] != ((uint64_t)c.n | ((uint64_t)c.k << 32)) || d[3] != c.q || d[4] != c.t) return false;
+    *body = d + kHeaderWords;
+    return true;
+}
+
+static int verify_opening(const LweContext& c, const LweCommitment* cm, const uint64_t* message, size_t msg_len) {
+    const uint64_t* body = nullptr;
+    if (!parse_commitment(c, cm, &body)) return -1;
+    const uint32_t n = c.n, k = c.k;
+    const size_t kn = (size_t)k * n;
+    for (size_t i = 0; i < kn + n; ++i)
+        if (body[i] >= c.q) return -1;                                      // not a canonical payload
+    if (msg_len > n) return 0;                                             // commitment.cpp:219-221
+    if (msg_len == 0) return 1;
+    DeviceGuard guard(c.device);
+    std::lock_guard<std::mutex> lock(c.mutex);
+    ensure_workspace(c, 1);
+    hipStream_t s = c.ntt->stream;
+    LSR_HIP(hipMemcpyAsync(c.ws_u.ptr, body, kn * 8, hipMemcpyHostToDevice, s));
+    LSR_HIP(hipMemcpyAsync(c.ws_v.ptr, body + kn, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    LSR_HIP(hipMemcpyAsync(c.ws_dm.ptr, message, msg_len * 8, hipMemcpyHostToDevice, s));
+    LSR_HIP(hipMemsetAsync(c.ws_flag.ptr, 0, sizeof(unsigned long long), s));
+    launch_ntt(*c.ntt, c.ws_u.ptr, k, false, s);
+    launch_ntt(*c.ntt, c.ws_v.ptr, 1, false, s);
+    // e2 <- <s_hat, u_hat>;  e2 <- v_hat - e2;  INTT
+    matvec(c, c.ws_e2.ptr, c.s_hat.ptr, c.ws_u.ptr, nullptr, 1, k, 0, 1, 1, s);
+    hipLaunchKernelGGL(rsub_mod_kernel, dim3(grid_for(n)), dim3(256), 0, s, c.ws_e2.ptr, c.ws_v.ptr, (uint64_t)n, c.q);
+    launch_ntt(*c.ntt, c.ws_e2.ptr, 1, true, s);
+    hipLaunchKernelGGL(decode_compare_kernel, dim3((unsigned)((msg_len + 255) / 256)), dim3(256), 0, s, c.ws_e2.ptr, c.ws_dm.ptr, (uint64_t)msg_len, c.t,
+                       c.ntt->mod, c.ws_flag.ptr);
+    LSR_HIP(hipGetLastError());
+    unsigned long long flag = 1;
+    LSR_HIP(hipMemcpyAsync(&flag, c.ws_flag.ptr, sizeof flag, hipMemcpyDeviceToHost, s));
+    LSR_HIP(hipStreamSynchronize(s));
+    return flag == 0 ? 1 : 0;
+}
+
+static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** cms, const uint64_t* coeffs, size_t count) {
+    const size_t body_words = (size_t)(c.k + 1) * c.n;
+    DeviceGuard guard(c.device);
+    std::lock_guard<std::mutex> lock(c.mutex);
+    ensure_workspace(c, 1);
+    hipStream_t s = c.ntt->stream;
+    DeviceBuffer<uint64_t> acc(body_words), term(body_words);
+    LSR_HIP(hipMemsetAsync(acc.ptr, 0, body_words * 8, s));
+    bool any = false;
+    for (size_t i = 0; i < count; ++i) {
+        if (!cms[i]) continue;                                             // commitment.cpp:248-250
+        const uint64_t* body = nullptr;
+        if (!parse_commitment(c, cms[i], &body)) {
+            (void)hipStreamSynchronize(s);
+            return nullptr;                                                // commitment.cpp:253-255
+        }
+        LSR_HIP(hipMemcpyAsync(term.ptr, body, body_words * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(axpy_mod_kernel, dim3(grid_for(body_words)), dim3(256), 0, s, acc.ptr, term.ptr, coeffs[i] % c.t, (uint64_t)body_words, c.ntt->mod);
+        LSR_HIP(hipGetLastError());
+        LSR_HIP(hipStreamSynchronize(s));   // `term` is reused
+        any = true;
+    }
+    if (!any) return nullptr;                                              // commitment.cpp:268-270
+    const size_t words = kHeaderWords + body_words;
+    LweCommitment* out = new_commitment(words);
+    out->data[0] = 8ull * (words - 1);
+    out->data[1] = kWireMagic;
+    out->data[2] = (uint64_t)c.n | ((uint64_t)c.k << 32);
+    out->data[3] = c.q;
+    out->data[4] = c.t;
+    try {
+        LSR_HIP(hipMemcpyAsync(out->data + kHeaderWords, acc.ptr, body_words * 8, hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipStreamSynchronize(s));
+    } catch (...) {
+        delete[] out->data;
+        delete out;
+        throw;
+    }
+    return out;
+}
+
+}  // namespace lsr
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+LweContext* lwe_context_create(const PublicParams* params) noexcept {
+    try {
+        uint64_t key_seed = 0;   // fresh key per context, like the reference (commitment.cpp:118-121)
+        if (const char* env = std::getenv("LAMBDA_SNARK_KEY_SEED")) key_seed = std::strtoull(env, nullptr, 0);
+        return lsr::create_lwe_context(params, key_seed, -1);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "lwe_context_create error: %s\n", e.what());
+        return nullptr;
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+LweContext* lsr_lwe_context_create_seeded(const PublicParams* params, uint64_t key_seed, int device) noexcept {
+    try {
+        return lsr::create_lwe_context(params, key_seed, device);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "lwe_context_create error: %s\n", e.what());
+        return nullptr;
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+void lwe_context_free(LweContext* ctx) noexcept { lsr::destroy_lwe_context(ctx); }
+
+uint64_t lsr_lwe_modulus(const LweContext* ctx) noexcept { return ctx ? ctx->q : 0; }
+uint64_t lsr_lwe_plain_modulus(const LweContext* ctx) noexcept { return ctx ? ctx->t : 0; }
+uint32_t lsr_lwe_ring_degree(const LweContext* ctx) noexcept { return ctx ? ctx->n : 0; }
+uint32_t lsr_lwe_module_rank(const LweContext* ctx) noexcept { return ctx ? ctx->k : 0; }
+size_t lsr_lwe_commitment_words(const LweContext* ctx) noexcept { return ctx ? lsr::kHeaderWords + (size_t)(ctx->k + 1) * ctx->n : 0; }
+const NttContext* lsr_lwe_ntt_context(const LweContext* ctx) noexcept { return ctx ? ctx->ntt : nullptr; }
+
+int lsr_lwe_public_matrix(const LweContext* ctx, uint64_t* a_hat) noexcept {
+    if (!ctx || !a_hat) return -1;
+    try {
+        lsr::DeviceGuard guard(ctx->device);
+        LSR_HIP(hipMemcpy(a_hat, ctx->a_hat.ptr, ctx->a_hat.count * 8, hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(e.what());
+        return -1;
+    }
+}
+
+int lwe_commit_batch(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, LweCommitment** out) noexcept {
+    if (!ctx || !messages || !out) return -1;
+    if (batch == 0) return 0;
+    try {
+        lsr::DeviceGuard guard(ctx->device);
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        const size_t per_commit = (3 * (size_t)ctx->k + 3) * ctx->n * 8;
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, (1ull << 30) / per_commit));
+        size_t done = 0;
+        try {
+            for (; done < batch; done += std::min(chunk, batch - done))
+                lsr::commit_chunk(*ctx, messages + done * msg_len, msg_len, std::min(chunk, batch - done), seeds ? seeds + done : nullptr, out + done);
+        } catch (...) {
+            for (size_t j = 0; j < done; ++j) { lwe_commitment_free(out[j]); out[j] = nullptr; }
+            throw;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lwe_commit_batch: ") + e.what());
+        std::fprintf(stderr, "lwe_commit error: %s\n", e.what());                 // commitment.cpp:158-160
+        return -1;
+    } catch (...) {
+        std::fprintf(stderr, "lwe_commit error: unknown exception\n");           // commitment.cpp:161-163
+        return -1;
+    }
+}
+
+LweCommitment* lwe_commit(LweContext* ctx, const uint64_t* message, size_t msg_len, uint64_t seed) noexcept {
+    if (!ctx || !message) return nullptr;                                          // commitment.cpp:144
+    LweCommitment* out = nullptr;
+    if (lwe_commit_batch(ctx, message, msg_len, 1, &seed, &out) != 0) return nullptr;
+    return out;
+}
+
+void lwe_commitment_free(LweCommitment* comm) noexcept {
+    if (!comm) return;
+    if (comm->data) {
+        volatile uint64_t* p = comm->data;                                         // zeroize (commitment.cpp:169-173)
+        for (size_t i = 0; i < comm->len; ++i) p[i] = 0;
+        delete[] comm->data;
+    }
+    delete comm;
+}
+
+LweCommitment* lwe_commitment_clone(const LweCommitment* comm) noexcept {
+    if (!comm || comm->len == 0 || !comm->data) return nullptr;                    // commitment.cpp:180-182
+    auto* clone = new (std::nothrow) LweCommitment;
+    if (!clone) return nullptr;
+    clone->len = comm->len;
+    clone->data = new (std::nothrow) uint64_t[clone->len];
+    if (!clone->data) {
+        delete clone;
+        return nullptr;
+    }
+    std::memcpy(clone->data, comm->data, clone->len * sizeof(uint64_t));
+    return clone;
+}
+
+int lwe_verify_opening(const LweContext* ctx, const LweCommitment* commitment, const uint64_t* message, size_t msg_len,
+                       const LweOpening* /*opening: ignored, commitment.cpp:205*/) noexcept {
+    if (!ctx || !commitment || !message) return -1;                                // commitment.cpp:207
+    try {
+        return lsr::verify_opening(*ctx, commitment, message, msg_len);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "lwe_verify_opening error: %s\n", e.what());         // commitment.cpp:229-231
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
+LweCommitment* lwe_linear_combine(const LweContext* ctx, const LweCommitment** commitments, const uint64_t* coeffs, size_t count) noexcept {
+    if (!ctx || !commitments || !coeffs || count == 0) return nullptr;             // commitment.cpp:240-242
+    try {
+        return lsr::linear_combine(*ctx, commitments, coeffs, count);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "lwe_linear_combine error: %s\n", e.what());         // commitment.cpp:273-275
+        return nullptr;
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, const uint64_t* seeds,
+                                 void* stream) noexcept {
+    if (!ctx || !d_r || !d_u) return -1;
+    if (!d_e1 && !seeds) return -1;
+    if (batch == 0) return 0;
+    try {
+        lsr::DeviceGuard guard(ctx->device);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (d_e1) {
+            lsr::mlwe_matvec_device(*ctx, d_r, d_e1, d_u, batch, s);
+            return 0;
+        }
+        // e1 sampled on the device from the per-commit seeds (domain 5), then added
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        lsr::ensure_workspace(*ctx, batch);
+        LSR_HIP(hipMemcpyAsync(ctx->ws_seeds.ptr, seeds, batch * 8, hipMemcpyHostToDevice, s));
+        lsr::launch_gaussian(lsr::GaussianJob{ctx->ws_e1.ptr, ctx->ws_seeds.ptr, 0, ctx->k, lsr::kDomE1, ctx->n, batch * ctx->k, ctx->q}, ctx->cdf.ptr,
+                             ctx->cdf_entries, s);
+        lsr::mlwe_matvec_device(*ctx, d_r, ctx->ws_e1.ptr, d_u, batch, s);
+        LSR_HIP(hipStreamSynchronize(s));   // seeds is a host array the caller may reuse
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lsr_mlwe_matvec_batch_device: ") + e.what());
+        std::fprintf(stderr, "lambda_snark_core: lsr_mlwe_matvec_batch_device failed: %s\n", e.what());
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
+}  // extern "C"

@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
 }
 
 // ---- pointwise product (ntt.cpp:106-119) ------------------------------------------------------------
-__global__ void __launch_bounds__(kThreads) pointwise_mul_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ a,
+static __global__ void __launch_bounds__(kThreads) pointwise_mul_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ a,
                                                                    const uint64_t* __restrict__ b, size_t count, ModParams p) {
     const size_t stride = (size_t)gridDim.x * kThreads;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += stride) out[i] = mulmod_barrett128(a[i], b[i], p);

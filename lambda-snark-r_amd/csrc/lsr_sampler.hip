@@ -1,0 +1,124 @@
+// Discrete-Gaussian / uniform sampling kernels and the sample_gaussian C-ABI
+// (reference: cpp-core/src/utils.cpp:132-146, header cpp-core/include/lambda_snark/utils.h:27).
+#include <cmath>
+#include <cstring>
+
+#include "lambda_snark/batch.h"
+#include "lambda_snark/utils.h"
+#include "lsr_runtime.hpp"
+#include "lsr_sampler.hpp"
+
+namespace lsr {
+
+constexpr int kSamplerThreads = 256;
+
+// One lane = one ChaCha block = four samples.  The CDT table sits in LDS.
+__global__ void __launch_bounds__(kSamplerThreads) gaussian_kernel(GaussianJob job, const uint64_t* __restrict__ cdf_global, uint32_t entries) {
+    extern __shared__ uint64_t cdf[];
+    for (uint32_t i = threadIdx.x; i < entries; i += kSamplerThreads) cdf[i] = cdf_global[i];
+    __syncthreads();
+    const uint64_t blocks_per_object = (job.samples + 3) >> 2;
+    const uint64_t gid = (uint64_t)blockIdx.x * kSamplerThreads + threadIdx.x;
+    if (gid >= blocks_per_object * job.objects) return;
+    const uint64_t object = gid / blocks_per_object;
+    const uint64_t block = gid - object * blocks_per_object;
+    const uint64_t seed = job.seeds[object / job.components];
+    const uint64_t index = job.index_base + object % job.components;
+    uint64_t w[8];
+    stream_block(seed, job.domain, index, (uint32_t)block, w);
+    uint64_t* dst = job.out + object * job.samples + block * 4;
+    const uint64_t left = job.samples - block * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if ((uint64_t)s >= left) break;
+        const uint32_t magnitude = cdt_lookup(cdf, entries, w[2 * s]);
+        const bool negative = (w[2 * s + 1] & 1ull) && magnitude != 0;
+        uint64_t value;
+        if (job.q) value = negative ? job.q - magnitude : (uint64_t)magnitude;
+        else value = negative ? (uint64_t)(-(int64_t)magnitude) : (uint64_t)magnitude;
+        dst[s] = value;
+    }
+}
+
+// One lane = one ChaCha block = eight uniform residues.
+__global__ void __launch_bounds__(kSamplerThreads) uniform_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ seeds, uint64_t index_base,
+                                                                    uint32_t components, uint32_t domain, uint64_t samples, uint64_t objects, uint64_t q) {
+    const uint64_t blocks_per_object = (samples + 7) >> 3;
+    const uint64_t gid = (uint64_t)blockIdx.x * kSamplerThreads + threadIdx.x;
+    if (gid >= blocks_per_object * objects) return;
+    const uint64_t object = gid / blocks_per_object;
+    const uint64_t block = gid - object * blocks_per_object;
+    uint64_t w[8];
+    stream_block(seeds[object / components], domain, index_base + object % components, (uint32_t)block, w);
+    uint64_t* dst = out + object * samples + block * 8;
+    const uint64_t left = samples - block * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        if ((uint64_t)s < left) dst[s] = __umul64hi(w[s], q);
+}
+
+void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream) {
+    const uint64_t lanes = ((job.samples + 3) >> 2) * job.objects;
+    if (!lanes) return;
+    const unsigned grid = static_cast<unsigned>((lanes + kSamplerThreads - 1) / kSamplerThreads);
+    hipLaunchKernelGGL(gaussian_kernel, dim3(grid), dim3(kSamplerThreads), entries * sizeof(uint64_t), stream, job, d_cdf, entries);
+    LSR_HIP(hipGetLastError());
+}
+
+void launch_uniform(uint64_t* out, const uint64_t* d_seeds, uint64_t index_base, uint32_t components, uint32_t domain, uint64_t samples,
+                    uint64_t objects, uint64_t q, hipStream_t stream) {
+    const uint64_t lanes = ((samples + 7) >> 3) * objects;
+    if (!lanes) return;
+    const unsigned grid = static_cast<unsigned>((lanes + kSamplerThreads - 1) / kSamplerThreads);
+    hipLaunchKernelGGL(uniform_kernel, dim3(grid), dim3(kSamplerThreads), 0, stream, out, d_seeds, index_base, components, domain, samples, objects, q);
+    LSR_HIP(hipGetLastError());
+}
+
+// host-buffer sampler used by both C-ABI entry points
+static int sample_to_host(uint64_t* output, size_t len, double sigma, uint64_t seed, uint32_t domain, uint64_t index) {
+    const std::vector<uint64_t> table = gaussian_cdf(sigma);
+    if (table.empty() || table.size() > 8000) throw std::runtime_error("sigma out of the supported range (table must fit LDS)");
+    if ((len + 3) / 4 > 0xFFFFFFFFull) throw std::runtime_error("len exceeds one stream (2^34 samples)");
+    if (visible_device_count() <= 0) throw std::runtime_error("no HIP device visible — no CPU fallback");
+    DeviceGuard guard(default_device());
+    DeviceBuffer<uint64_t> d_cdf, d_seed, d_out(len);
+    d_cdf.upload(table);
+    d_seed.upload(std::vector<uint64_t>{seed});
+    GaussianJob job{d_out.ptr, d_seed.ptr, index, 1, domain, len, 1, 0};
+    launch_gaussian(job, d_cdf.ptr, static_cast<uint32_t>(table.size()), nullptr);
+    LSR_HIP(hipMemcpy(output, d_out.ptr, len * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // namespace lsr
+
+extern "C" {
+
+int sample_gaussian(uint64_t* output, size_t len, double sigma) noexcept {
+    if (!output || len == 0 || !(sigma > 0.0) || !std::isfinite(sigma)) return -1;   // utils.cpp:133
+    try {
+        // fresh entropy per call, as the reference's std::random_device (utils.cpp:138)
+        return lsr::sample_to_host(output, len, sigma, lsr::os_entropy64(), lsr::kDomUser, lsr::os_entropy64());
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("sample_gaussian: ") + e.what());
+        std::fprintf(stderr, "lambda_snark_core: sample_gaussian failed: %s\n", e.what());
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
+int lsr_sample_gaussian_seeded(uint64_t* output, size_t len, double sigma, uint64_t seed, uint32_t domain, uint64_t index) noexcept {
+    if (!output || len == 0 || !(sigma > 0.0) || !std::isfinite(sigma)) return -1;
+    try {
+        return lsr::sample_to_host(output, len, sigma, seed, domain, index);
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lsr_sample_gaussian_seeded: ") + e.what());
+        std::fprintf(stderr, "lambda_snark_core: lsr_sample_gaussian_seeded failed: %s\n", e.what());
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
+}  // extern "C"

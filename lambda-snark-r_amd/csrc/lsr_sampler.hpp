@@ -1,0 +1,79 @@
+// Seeded randomness on the device: ChaCha20 word stream, uniform residues, CDT discrete Gaussian.
+//
+// The reference sampler (cpp-core/src/utils.cpp:95-146) draws two 64-bit words per sample from
+// std::random_device: one compared against the CDT table (first k with cdf[k] >= u), one whose low bit is
+// the sign.  Here the words come from a counter-based ChaCha20 stream so that a seed reproduces the
+// output on any device: object (seed, domain, index) owns a stream; 64-bit word w of it is ChaCha block
+// w/8, 32-bit words 2(w%8) (low half) and 2(w%8)+1 (high half); sample i uses words 2i and 2i+1.
+//   key   = { seed_lo, seed_hi, "LSR1", "STRM", 0, 0, 0, 0 }
+//   nonce = { domain, index_lo, index_hi }          counter = block number
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace lsr {
+
+enum StreamDomain : uint32_t { kDomA = 1, kDomS = 2, kDomE = 3, kDomR = 4, kDomE1 = 5, kDomE2 = 6, kDomUser = 16 };
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+
+__device__ __forceinline__ void chacha_quarter(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+    a += b; d ^= a; d = rotl32(d, 16);
+    c += d; b ^= c; b = rotl32(b, 12);
+    a += b; d ^= a; d = rotl32(d, 8);
+    c += d; b ^= c; b = rotl32(b, 7);
+}
+
+// RFC 8439 §2.3 block function; returns the block as eight little-endian 64-bit words.
+__device__ __forceinline__ void stream_block(uint64_t seed, uint32_t domain, uint64_t index, uint32_t block, uint64_t (&w)[8]) {
+    const uint32_t init[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), 0x3152534Cu, 0x4D525453u, 0u, 0u, 0u, 0u,
+                               block, domain, (uint32_t)index, (uint32_t)(index >> 32)};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = init[i];
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        chacha_quarter(x[0], x[4], x[8], x[12]);
+        chacha_quarter(x[1], x[5], x[9], x[13]);
+        chacha_quarter(x[2], x[6], x[10], x[14]);
+        chacha_quarter(x[3], x[7], x[11], x[15]);
+        chacha_quarter(x[0], x[5], x[10], x[15]);
+        chacha_quarter(x[1], x[6], x[11], x[12]);
+        chacha_quarter(x[2], x[7], x[8], x[13]);
+        chacha_quarter(x[3], x[4], x[9], x[14]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = (uint64_t)(x[2 * j] + init[2 * j]) | ((uint64_t)(x[2 * j + 1] + init[2 * j + 1]) << 32);
+}
+
+// first k with cdf[k] >= u (cdf non-decreasing, cdf[entries-1] == 2^64-1) — same value the reference's
+// branch-free scan selects (utils.cpp:101-108)
+__device__ __forceinline__ uint32_t cdt_lookup(const uint64_t* cdf, uint32_t entries, uint64_t u) {
+    uint32_t lo = 0, hi = entries - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] >= u) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+struct GaussianJob {
+    uint64_t* out;            // [objects][samples]
+    const uint64_t* seeds;    // device array; object o uses seeds[o / components]
+    uint64_t index_base;      // stream index of object o = index_base + o % components
+    uint32_t components;
+    uint32_t domain;
+    uint64_t samples;         // per object
+    uint64_t objects;
+    uint64_t q;               // 0: two's-complement int64 (utils.cpp:142); else residue in [0,q)
+};
+
+void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream);
+// out[o][i] = floor(word_i * q / 2^64), object o = (seeds[o / components], domain, index_base + o % components)
+void launch_uniform(uint64_t* out, const uint64_t* d_seeds, uint64_t index_base, uint32_t components, uint32_t domain,
+                    uint64_t samples, uint64_t objects, uint64_t q, hipStream_t stream);
+
+}  // namespace lsr

@@ -1,0 +1,238 @@
+"""CPU suite, part 1: the oracle is pinned before anything trusts it.
+
+Pins: the survey's check values (psi, heads, SHA-256), the mathematical definition of the
+transform (independent O(n^2) evaluation), the reference's own test assertions restated
+(cpp-core/tests/test_ntt.cpp, test_utils.cpp, test_commitment.cpp), the ROOTS_OF_UNITY table of
+rust-api/lambda-snark/src/r1cs.rs:534-547, RFC 8439 for the stream, and this repo's regression vectors.
+Forward-NTT *values* are not pinned by any reference test (the reference holds no KAT and cannot be built
+here) — see DESIGN.md.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+Q12, Q44, Q16 = 12289, 17592169062401, 17592182243329
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def check_values(golden_dir):
+    with open(os.path.join(golden_dir, "ntt_check_values.json")) as f:
+        return json.load(f)
+
+
+def test_survey_check_values(oracle, check_values):
+    for case in check_values["cases"]:
+        q, n = case["q"], case["n"]
+        a = oracle.splitmix(check_values["splitmix_seed"], q, n)
+        assert [int(x) for x in a[:3]] == case["a"]
+        assert oracle.root(q, n) == case["psi"]
+        f = oracle.ntt_forward(q, n, a)
+        assert [int(x) for x in f[:3]] == case["ntt"]
+        assert sha(f) == case["sha256"]
+        assert np.array_equal(oracle.ntt_inverse(q, n, f), a)
+
+
+def test_roots_of_unity_kat(oracle, check_values):
+    r = check_values["roots_of_unity"]
+    q = r["q"]
+    for m, w in r["table"]:
+        assert oracle.L.oracle_powmod(r["generator"], (q - 1) // m, q) == w
+        assert oracle.L.oracle_powmod(w, m, q) == 1 and oracle.L.oracle_powmod(w, m // 2, q) == q - 1
+
+
+@pytest.mark.parametrize("q,n", [(Q12, 2), (Q12, 4), (Q12, 64), (Q12, 256), (Q44, 512), (Q44, 1024)])
+def test_forward_matches_definition(oracle, q, n):
+    """out[i] = a(psi^(2*bitrev(i)+1)) — SURVEY.md §8(a) N3 — by direct Horner evaluation."""
+    a = oracle.splitmix(1234 + n, q, n)
+    assert np.array_equal(oracle.ntt_forward(q, n, a), oracle.ntt_forward_naive(q, n, a))
+
+
+def test_psi_is_minimal_primitive_root(oracle):
+    for q, n in [(Q12, 256), (Q12, 2048), (Q44, 4096)]:
+        psi = oracle.root(q, n)
+        assert pow(psi, n, q) == q - 1
+        # brute force over all primitive 2n-th roots for the small prime
+        if q == Q12:
+            prim = [x for x in range(2, q) if pow(x, n, q) == q - 1]
+            assert psi == min(prim)
+
+
+def test_negacyclic_convolution_theorem(oracle):
+    q, n = Q12, 256
+    a, b = oracle.splitmix(1, q, n), oracle.splitmix(2, q, n)
+    prod = oracle.ntt_inverse(q, n, oracle.mul_pointwise(q, n, oracle.ntt_forward(q, n, a), oracle.ntt_forward(q, n, b)))
+    school = np.zeros(n, dtype=object)
+    for i in range(n):
+        for j in range(n):
+            k = i + j
+            term = int(a[i]) * int(b[j])
+            if k >= n:
+                school[k - n] -= term
+            else:
+                school[k] += term
+    assert [int(x) % q for x in school] == [int(x) for x in prod]
+
+
+def test_reference_test_ntt_cpp_pins(oracle):
+    """cpp-core/tests/test_ntt.cpp:47-81 restated on the oracle."""
+    q, n = Q12, 256
+    x = np.zeros(n, dtype=np.uint64)
+    x[:8] = np.arange(1, 9)
+    assert np.array_equal(oracle.ntt_inverse(q, n, oracle.ntt_forward(q, n, x)), x)
+    assert np.array_equal(oracle.mul_pointwise(q, n, np.full(n, 2, np.uint64), np.full(n, 3, np.uint64)), np.full(n, 6, np.uint64))
+
+
+def test_context_creation_rules(oracle):
+    """ntt.cpp:30-70 + SEAL constructor rules."""
+    ok = oracle.ntt_create_ok
+    assert ok(Q12, 256) and ok(Q44, 4096) and ok(Q44, 2) and ok(Q16, 65536) and ok(1152921504606584833, 131072)
+    assert not ok(Q12, 0)                       # n == 0
+    assert not ok(Q12, 3) and not ok(Q12, 48)   # not a power of two
+    assert not ok(Q12, 1)                       # log n < 1
+    assert not ok(1152921504606584833, 262144)  # log n > 17
+    assert not ok(Q44, 65536)                   # F5: q-1 = 2^13 * odd
+    assert not ok(2**64 - 2**32 + 1, 256)       # >= 2^61
+    assert not ok(17592186044417, 4096)         # 2^44+1 is composite
+    assert not ok(17592186044423, 4096)         # prime but q-1 = 2 * odd
+    assert not ok(Q12, 4096)                    # 8192 does not divide 12288
+    assert not ok(0, 256) and not ok(1, 256)
+
+
+def test_lazy_input_tolerance(oracle):
+    """N3: inputs < 4q are tolerated and give the result of the reduced input."""
+    q, n = Q44, 1024
+    a = oracle.splitmix(5, q, n)
+    assert np.array_equal(oracle.ntt_forward(q, n, a + np.uint64(3 * q)), oracle.ntt_forward(q, n, a))
+
+
+# ---------------------------------------------------------------- sampler (cpp-core/tests/test_utils.cpp)
+def test_sampler_rejects_invalid(oracle):
+    assert oracle.L.oracle_sample_gaussian(None, 16, 3.2) == -1
+    buf = np.zeros(16, dtype=np.uint64)
+    assert oracle.L.oracle_sample_gaussian(buf.ctypes.data, 0, 3.2) == -1
+    assert oracle.L.oracle_sample_gaussian(buf.ctypes.data, 16, 0.0) == -1
+    assert oracle.L.oracle_sample_gaussian(buf.ctypes.data, 16, float("inf")) == -1
+
+
+def _moments_ok(v, sigma):
+    v = v.astype(np.float64)
+    pos, neg = int((v > 0).sum()), int((v < 0).sum())
+    return abs(v.mean()) < 0.5 and abs(v.std(ddof=1) - sigma) < 0.8 and pos > v.size / 4 and neg > v.size / 4 and abs(pos - neg) < v.size / 5
+
+
+def test_sampler_moments(oracle):
+    rc, v = oracle.sample_gaussian(4096, 3.2)
+    assert rc == 0 and _moments_ok(v, 3.2)
+    assert _moments_ok(oracle.sample_gaussian_seeded(4096, 3.2, 42, 16, 0), 3.2)
+
+
+def test_cdf_table_shape(oracle):
+    """utils.cpp:26-75: bound = max(8, ceil(12 sigma)), monotone, last forced to 2^64-1, cdf[0] ~ 1/sum."""
+    for sigma, entries in [(3.19, 40), (0.3, 9), (1.0, 13), (3.2, 40)]:
+        cdf = oracle.gaussian_cdf(sigma)
+        assert cdf.size == entries
+        assert cdf[-1] == np.uint64(2**64 - 1)
+        assert all(int(cdf[i]) <= int(cdf[i + 1]) for i in range(cdf.size - 1))
+    cdf = oracle.gaussian_cdf(3.19)
+    total = 1 + 2 * sum(np.exp(-k * k / (2 * 3.19**2)) for k in range(1, 40))
+    assert abs(int(cdf[0]) / 2**64 - 1 / total) < 1e-12
+
+
+def test_chacha20_rfc8439(oracle, golden_dir):
+    with open(os.path.join(golden_dir, "rfc8439_chacha20.json")) as f:
+        v = json.load(f)
+    key = np.frombuffer(bytes.fromhex(v["key_bytes_hex"]), dtype="<u4")
+    nonce = np.frombuffer(bytes.fromhex(v["nonce_bytes_hex"]), dtype="<u4")
+    out = oracle.chacha20_block(key, v["counter"], nonce)
+    assert [f"{int(x):08x}" for x in out] == v["output_words_hex"]
+
+
+def test_stream_is_counter_based(oracle):
+    a = oracle.stream_words(99, 5, 3, 0, 64)
+    assert np.array_equal(oracle.stream_words(99, 5, 3, 17, 20), a[17:37])
+    assert not np.array_equal(oracle.stream_words(99, 5, 4, 0, 8), a[:8])
+    assert not np.array_equal(oracle.stream_words(99, 4, 3, 0, 8), a[:8])
+    assert not np.array_equal(oracle.stream_words(98, 5, 3, 0, 8), a[:8])
+
+
+# ---------------------------------------------------------------- commitment (cpp-core/tests/test_commitment.cpp)
+P = dict(q=12289, n=4096, k=2, sigma=3.19, key_seed=0xABCDEF)
+
+
+def test_commitment_parameter_selection(oracle):
+    sel = oracle.L.oracle_lwe_select_modulus
+    assert sel(12289, 4096) == Q44                  # test_commitment.cpp:15 passes q=12289 with n=4096
+    assert sel(17592186044417, 4096) == Q44         # every Rust caller: 2^44+1 (composite)
+    assert sel(17592186044423, 4096) == Q44
+    assert sel(Q44, 4096) == Q44
+    assert sel(Q16, 65536) == Q16 and sel(12289, 65536) == Q16
+    assert sel(1152921504606584833, 4096) == 1152921504606584833
+    assert sel(Q44, 1) == 0 and sel(Q44, 3) == 0
+    assert oracle.L.oracle_largest_prime_1mod(8192, 20) == 1032193   # SEAL Batching(4096,20) = 0xfc001
+
+
+def test_commit_basic_and_binding(oracle):
+    c1 = oracle.lwe_commit(msg=[1, 2, 3], seed=0x1234, **P)
+    c2 = oracle.lwe_commit(msg=[4, 5, 6], seed=0x1234, **P)
+    assert c1.size == 1 + 4 + 3 * 4096 and c1[0] == 8 * (c1.size - 1)
+    assert not np.array_equal(c1, c2)                                        # test_commitment.cpp:77-100
+    assert np.array_equal(c1, oracle.lwe_commit(msg=[1, 2, 3], seed=0x1234, **P))   # seed => deterministic (commitment.h:52)
+    assert not np.array_equal(c1, oracle.lwe_commit(msg=[1, 2, 3], seed=0x1235, **P))
+
+
+def test_verify_opening(oracle):
+    msg = [7, 11, 13, 17]
+    c = oracle.lwe_commit(msg=msg, seed=77, **P)
+    assert oracle.lwe_verify(comm_words=c, msg=msg, **P) == 1                # test_commitment.cpp:115-132
+    assert oracle.lwe_verify(comm_words=c, msg=[7, 10, 13, 17], **P) == 0
+    assert oracle.lwe_verify(comm_words=c, msg=[0] * 4097, **P) == 0         # msg_len > slots
+    bad = c.copy(); bad[0] = 0
+    assert oracle.lwe_verify(comm_words=bad, msg=msg, **P) == -1             # commitment.cpp:71-75
+    assert oracle.lwe_verify(comm_words=c[:100], msg=msg, **P) == -1
+
+
+def test_linear_combination(oracle):
+    m1, m2 = [1, 2, 3, 4], [5, 6, 7, 8]
+    c1 = oracle.lwe_commit(msg=m1, seed=1, **P)
+    c2 = oracle.lwe_commit(msg=m2, seed=2, **P)
+    rc, comb = oracle.lwe_linear_combine(comms=[c1, c2], coeffs=[2, 3], **P)
+    assert rc == 0
+    expected = [2 * a + 3 * b for a, b in zip(m1, m2)]
+    assert oracle.lwe_verify(comm_words=comb, msg=expected, **P) == 1         # test_commitment.cpp:134-166
+    expected[0] += 1
+    assert oracle.lwe_verify(comm_words=comb, msg=expected, **P) == 0
+
+
+def test_commit_truncates_and_pads(oracle):
+    small = dict(q=12289, n=64, k=1, sigma=3.19, key_seed=5)
+    long_msg = list(range(1, 101))
+    c = oracle.lwe_commit(msg=long_msg, seed=3, **small)
+    assert np.array_equal(c, oracle.lwe_commit(msg=long_msg[:64], seed=3, **small))   # commitment.cpp:146-149
+    assert oracle.lwe_verify(comm_words=c, msg=long_msg[:64], **small) == 1
+    assert oracle.lwe_verify(comm_words=c, msg=long_msg[:10] , **small) == 1
+
+
+def test_oracle_regression_vectors(oracle, golden_dir):
+    with open(os.path.join(golden_dir, "oracle_regression.json")) as f:
+        g = json.load(f)
+    for e in g["ntt"]:
+        a = oracle.splitmix(e["seed"], e["q"], e["n"])
+        f_ = oracle.ntt_forward(e["q"], e["n"], a)
+        assert oracle.root(e["q"], e["n"]) == e["psi"]
+        assert [int(x) for x in f_[:8]] == e["fwd_head"] and sha(f_) == e["fwd_sha256"]
+        assert sha(oracle.ntt_inverse(e["q"], e["n"], a)) == e["inv_of_input_sha256"]
+    s = g["sampler"]
+    cdf = oracle.gaussian_cdf(s["sigma"])
+    assert cdf.size == s["cdf_len"] and sha(cdf) == s["cdf_sha256"]
+    assert [int(x) for x in oracle.sample_gaussian_seeded(32, s["sigma"], 0x1234, 5, 1)] == s["seeded_head"]
+    assert [int(x) for x in oracle.stream_words(0x1234, 5, 1, 0, 4)] == s["stream_head"]
+    for e in g["commit"]:
+        c = oracle.lwe_commit(e["q"], e["n"], e["k"], e["sigma"], e["key_seed"], e["msg"], e["seed"])
+        assert c.size == e["words"] and [int(x) for x in c[:8]] == e["head"] and sha(c) == e["sha256"]
