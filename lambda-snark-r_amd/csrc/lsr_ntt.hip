@@ -122,6 +122,11 @@ NttContext* create_ntt_context(uint64_t q, uint32_t n, int device) {
         }
         ctx->staging.allocate(3ull * n);
         LSR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            LSR_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+            LSR_HIP(hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming));
+        }
+        LSR_HIP(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
     } catch (const std::exception& e) {
         set_last_error(std::string("ntt_context_create: ") + e.what());
         std::fprintf(stderr, "lambda_snark_core: ntt_context_create failed: %s\n", e.what());
@@ -136,6 +141,11 @@ void destroy_ntt_context(NttContext* ctx) {
     try {
         DeviceGuard guard(ctx->device);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
+            if (ctx->join_event[i]) (void)hipEventDestroy(ctx->join_event[i]);
+        }
+        if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
         ctx->staging.release();
         ctx->fwd_f64.release();
         ctx->inv_f64.release();
@@ -222,6 +232,25 @@ static void small_inverse(const NttContext& c, uint64_t* d, size_t total, hipStr
     }
 }
 
+static size_t ntt_chunk_bytes() {
+    static const size_t bytes = [] {
+        if (const char* e = std::getenv("LAMBDA_SNARK_NTT_CHUNK_MIB")) {
+            const long v = std::atol(e);
+            if (v > 0) return static_cast<size_t>(v) << 20;
+        }
+        return static_cast<size_t>(64) << 20;
+    }();
+    return bytes;
+}
+
+static bool ntt_overlap_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("LAMBDA_SNARK_NTT_OVERLAP");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 template <class A>
 static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s) {
     const size_t total = batch << c.logn;
@@ -235,14 +264,36 @@ static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse
     const int extra = c.logn - kTileLog;
     const int r_top = std::min(4, extra);
     const int r_low = extra - r_top;   // 0 or 1
-    if (!inverse) {
-        strided<A, false, false, true>(c, d, total, c.logn - r_top, r_top, s);
-        if (r_low) strided<A, false, true, true>(c, d, total, kTileLog, r_low, s);
-        tile_fwd<A, 12, true, false>(c, d, total, s);
-    } else {
-        tile_inv<A, 12, false, true>(c, d, total, s);
-        if (r_low) strided<A, true, true, true>(c, d, total, kTileLog, r_low, s);
-        strided<A, true, true, false>(c, d, total, c.logn - r_top, r_top, s);
+    // Walk the batch in chunks small enough that the array written by one pass is still resident in the
+    // 256 MiB Infinity Cache when the next pass reads it (MI355X_MICROARCH.md "Infinity Cache").
+    const size_t chunk_polys = std::max<size_t>(1, ntt_chunk_bytes() >> (c.logn + 3));
+    const bool overlap = ntt_overlap_enabled() && batch > chunk_polys;
+    if (overlap) {
+        LSR_HIP(hipEventRecord(c.fork_event, s));
+        LSR_HIP(hipStreamWaitEvent(c.side[0], c.fork_event, 0));
+        LSR_HIP(hipStreamWaitEvent(c.side[1], c.fork_event, 0));
+    }
+    size_t chunk_index = 0;
+    for (size_t first = 0; first < batch; first += chunk_polys, ++chunk_index) {
+        const size_t now = std::min(chunk_polys, batch - first);
+        uint64_t* base = d + (first << c.logn);
+        const size_t count = now << c.logn;
+        hipStream_t cs = overlap ? c.side[chunk_index & 1] : s;
+        if (!inverse) {
+            strided<A, false, false, true>(c, base, count, c.logn - r_top, r_top, cs);
+            if (r_low) strided<A, false, true, true>(c, base, count, kTileLog, r_low, cs);
+            tile_fwd<A, 12, true, false>(c, base, count, cs);
+        } else {
+            tile_inv<A, 12, false, true>(c, base, count, cs);
+            if (r_low) strided<A, true, true, true>(c, base, count, kTileLog, r_low, cs);
+            strided<A, true, true, false>(c, base, count, c.logn - r_top, r_top, cs);
+        }
+    }
+    if (overlap) {
+        for (int i = 0; i < 2; ++i) {
+            LSR_HIP(hipEventRecord(c.join_event[i], c.side[i]));
+            LSR_HIP(hipStreamWaitEvent(s, c.join_event[i], 0));
+        }
     }
 }
 

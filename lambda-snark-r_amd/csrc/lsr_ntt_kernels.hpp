@@ -7,7 +7,9 @@
 //   * tile kernel   — one 256-lane workgroup owns 4096 contiguous residues (one n=4096 polynomial, or
 //     4096/n smaller ones, or one 4096-block of a larger one) and runs every round on index bits
 //     [0,12) with the tile staged in LDS between rounds (padded so that every ds_read/ds_write_b64
-//     of a round is bank-conflict free); global traffic is fully coalesced on both ends.
+//     of a round is bank-conflict free); global traffic is fully coalesced on both ends.  The 15
+//     twiddles a lane needs for round r+1 are requested before the butterflies of round r start, so
+//     their L2 latency hides behind 256 FP64 instructions.
 //   * strided round kernel — index bits >= 12 (n > 4096): 16 registers hold residues n/16 apart, all
 //     256 lanes of a workgroup walk consecutive addresses, no LDS.
 // The intermediate array between two kernels of one transform is private, so it is left in the
@@ -26,6 +28,7 @@ constexpr int kTileLog = 12;
 constexpr uint32_t kTile = 1u << kTileLog;
 constexpr int kThreads = 256;
 constexpr int kRegs = 16;
+constexpr int kRoundTwiddles = 15;
 constexpr uint32_t kLdsWords = kTile + (kTile >> 4);   // one pad word per 16
 
 template <class A>
@@ -43,6 +46,25 @@ template <class A> __device__ __forceinline__ typename A::elem elem_from_bits(ui
 template <> __device__ __forceinline__ double elem_from_bits<ArithF64>(uint64_t b) { return __longlong_as_double((long long)b); }
 template <> __device__ __forceinline__ uint64_t elem_from_bits<ArithU64>(uint64_t b) { return b; }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Round schedule of the tile kernel for LT transformed bits: full radix-16 rounds from the top bit down,
+// then one remainder round of LT%4 bits at the bottom.  The inverse runs the same rounds in reverse.
+template <int LT, int I>
+struct TileRound {
+    static constexpr int kFull = LT / 4;
+    static constexpr int kRem = LT % 4;
+    static constexpr int kCount = kFull + (kRem ? 1 : 0);
+    static constexpr int R = I < kFull ? 4 : kRem;
+    static constexpr int LO = I < kFull ? LT - 4 * (I + 1) : 0;
+};
+
 // Tile index of register k for lane t in a round that keeps bits [LO, LO+R) in registers.  With R < 4
 // a lane carries 2^(4-R) independent groups; their selector goes to the top tile bits [8+R, 12).
 template <int LO, int R>
@@ -54,25 +76,45 @@ __host__ __device__ constexpr uint32_t reg_offset(int k) {
     return (uint32_t)((k & ((1 << R) - 1)) << LO) | (uint32_t)((k >> R) << (8 + R));
 }
 
-// ---- butterflies of one round, forward (Cooley–Tukey, high bit first) -----------------------------
-template <class A, int LO, int R>
-__device__ __forceinline__ void forward_round(typename A::elem (&v)[kRegs], uint32_t base_idx, uint32_t block_pos,
-                                              uint32_t nmask, const ModParams& p, const typename A::twid* __restrict__ tw) {
+// ---- twiddles of one round into registers -------------------------------------------------------------
+// Order: group, then stage in execution order (forward: high bit first; inverse: low bit first), then u.
+// SKIP_TOP: the stage of bit LO+R-1 takes its multipliers from RoundConsts (last inverse stage).
+template <class A, int LO, int R, bool INVERSE, bool SKIP_TOP>
+__device__ __forceinline__ void load_round_twiddles(typename A::twid (&w)[kRoundTwiddles], uint32_t base_idx, uint32_t block_pos,
+                                                    uint32_t nmask, int logn, const typename A::twid* __restrict__ tw) {
     constexpr int G = 1 << (4 - R);
+    int slot = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const uint32_t pos0 = (block_pos + (base_idx | ((uint32_t)g << (8 + R)))) & nmask;
 #pragma unroll
-        for (int b = LO + R - 1; b >= LO; --b) {
-            const int half = 1 << (b - LO);
-            const uint32_t tw_base = (1u << (p.logn - 1 - b)) + (pos0 >> (b + 1));
+        for (int step = 0; step < R; ++step) {
+            const int b = INVERSE ? LO + step : LO + R - 1 - step;
+            if (SKIP_TOP && b == LO + R - 1) continue;
+            const uint32_t tw_base = (1u << (logn - 1 - b)) + (pos0 >> (b + 1));
 #pragma unroll
-            for (int u = 0; u < (1 << (LO + R - 1 - b)); ++u) {
-                const typename A::twid w = A::load_tw(tw, tw_base + u);
+            for (int u = 0; u < (1 << (LO + R - 1 - b)); ++u) w[slot++] = A::load_tw(tw, tw_base + u);
+        }
+    }
+}
+
+// ---- butterflies of one round, forward (Cooley–Tukey, high bit first) -----------------------------
+template <class A, int LO, int R>
+__device__ __forceinline__ void forward_round(typename A::elem (&v)[kRegs], const typename A::twid (&w)[kRoundTwiddles], const ModParams& p) {
+    constexpr int G = 1 << (4 - R);
+    int slot = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int j = R - 1; j >= 0; --j) {          // register bit j <-> index bit LO + j
+            const int half = 1 << j;
+#pragma unroll
+            for (int u = 0; u < (1 << (R - 1 - j)); ++u) {
+                const typename A::twid tw = w[slot++];
 #pragma unroll
                 for (int l = 0; l < half; ++l) {
-                    const int kx = (g << R) | (u << (b - LO + 1)) | l;
-                    A::ct(v[kx], v[kx + half], w, p);
+                    const int kx = (g << R) | (u << (j + 1)) | l;
+                    A::ct(v[kx], v[kx + half], tw, p);
                 }
             }
         }
@@ -80,27 +122,29 @@ __device__ __forceinline__ void forward_round(typename A::elem (&v)[kRegs], uint
 }
 
 // ---- butterflies of one round, inverse (Gentleman–Sande, low bit first) ---------------------------
-template <class A, int LO, int R>
-__device__ __forceinline__ void inverse_round(typename A::elem (&v)[kRegs], uint32_t base_idx, uint32_t block_pos,
-                                              uint32_t nmask, const ModParams& p, const typename A::twid* __restrict__ tw,
+// FINAL: bit LO+R-1 is the transform's last stage (n^-1 folded in, SEAL transform_from_rev's scalar path)
+template <class A, int LO, int R, bool FINAL>
+__device__ __forceinline__ void inverse_round(typename A::elem (&v)[kRegs], const typename A::twid (&w)[kRoundTwiddles], const ModParams& p,
                                               const RoundConsts<A>& cs) {
     constexpr int G = 1 << (4 - R);
+    int slot = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const uint32_t pos0 = (block_pos + (base_idx | ((uint32_t)g << (8 + R)))) & nmask;
 #pragma unroll
-        for (int b = LO; b < LO + R; ++b) {
-            const int half = 1 << (b - LO);
-            const bool last_stage = (b == p.logn - 1);   // wave-uniform
-            const uint32_t tw_base = (1u << (p.logn - 1 - b)) + (pos0 >> (b + 1));
+        for (int j = 0; j < R; ++j) {
+            const int half = 1 << j;
+            if (FINAL && j == R - 1) {
 #pragma unroll
-            for (int u = 0; u < (1 << (LO + R - 1 - b)); ++u) {
-                const typename A::twid w = A::load_tw(tw, tw_base + u);
+                for (int l = 0; l < half; ++l) A::gs_scaled(v[(g << R) | l], v[((g << R) | l) + half], cs.w_last_scaled, cs.n_inv, p);
+                continue;
+            }
+#pragma unroll
+            for (int u = 0; u < (1 << (R - 1 - j)); ++u) {
+                const typename A::twid tw = w[slot++];
 #pragma unroll
                 for (int l = 0; l < half; ++l) {
-                    const int kx = (g << R) | (u << (b - LO + 1)) | l;
-                    if (last_stage) A::gs_scaled(v[kx], v[kx + half], cs.w_last_scaled, cs.n_inv, p);
-                    else A::gs(v[kx], v[kx + half], w, p);
+                    const int kx = (g << R) | (u << (j + 1)) | l;
+                    A::gs(v[kx], v[kx + half], tw, p);
                 }
             }
         }
@@ -115,47 +159,71 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restric
                                                                const typename A::twid* __restrict__ tw) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
+    using twid = typename A::twid;
+    constexpr int NR = TileRound<LT, 0>::kCount;
     const uint32_t t = threadIdx.x;
     const size_t tile_base = (size_t)blockIdx.x * kTile;
     const uint32_t nmask = (1u << p.logn) - 1u;
     const uint32_t block_pos = (uint32_t)(tile_base & nmask);
+    const bool full_tile = tile_base + kTile <= total;   // block-uniform
     elem v[kRegs];
+    twid w[2][kRoundTwiddles];
 
-    auto run_round = [&](auto lo_tag, auto r_tag, bool first) {
-        constexpr int LO = decltype(lo_tag)::value;
-        constexpr int R = decltype(r_tag)::value;
+    {   // first round: operands straight from global memory in the round's own mapping
+        constexpr int LO = TileRound<LT, 0>::LO, R = TileRound<LT, 0>::R;
         const uint32_t base = lane_base<LO, R>(t);
-        if (first) {
+        uint64_t raw[kRegs];
+        if (full_tile) {
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k) raw[k] = data[tile_base + (base | reg_offset<LO, R>(k))];
+        } else {
 #pragma unroll
             for (int k = 0; k < kRegs; ++k) {
                 const size_t gi = tile_base + (base | reg_offset<LO, R>(k));
-                const uint64_t raw = gi < total ? data[gi] : 0;
-                v[k] = RAW_IN ? elem_from_bits<A>(raw) : A::load(raw, p);
+                raw[k] = gi < total ? data[gi] : 0;
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < kRegs; ++k) v[k] = elem_from_bits<A>(lds[lds_slot(base | reg_offset<LO, R>(k))]);
         }
-        forward_round<A, LO, R>(v, base, block_pos, nmask, p, tw);
+        load_round_twiddles<A, LO, R, false, false>(w[0], base, block_pos, nmask, p.logn, tw);
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k) v[k] = RAW_IN ? elem_from_bits<A>(raw[k]) : A::load(raw[k], p);
+    }
+
+    static_for<0, NR>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        constexpr int LO = TileRound<LT, I>::LO, R = TileRound<LT, I>::R;
+        const uint32_t base = lane_base<LO, R>(t);
+        if constexpr (I + 1 < NR) {   // request the next round's twiddles before this round's arithmetic
+            constexpr int LO1 = TileRound<LT, I + 1>::LO, R1 = TileRound<LT, I + 1>::R;
+            load_round_twiddles<A, LO1, R1, false, false>(w[(I + 1) & 1], lane_base<LO1, R1>(t), block_pos, nmask, p.logn, tw);
+        }
+        forward_round<A, LO, R>(v, w[I & 1], p);
 #pragma unroll
         for (int k = 0; k < kRegs; ++k) lds[lds_slot(base | reg_offset<LO, R>(k))] = elem_bits<A>(v[k]);
         __syncthreads();
-    };
-
-    constexpr int REM = LT % 4;
-    constexpr int FULL = LT / 4;
-    if constexpr (FULL >= 1) run_round(std::integral_constant<int, LT - 4>{}, std::integral_constant<int, 4>{}, true);
-    if constexpr (FULL >= 2) run_round(std::integral_constant<int, LT - 8>{}, std::integral_constant<int, 4>{}, false);
-    if constexpr (FULL >= 3) run_round(std::integral_constant<int, LT - 12>{}, std::integral_constant<int, 4>{}, false);
-    if constexpr (REM > 0) run_round(std::integral_constant<int, 0>{}, std::integral_constant<int, REM>{}, FULL == 0);
+        if constexpr (I + 1 < NR) {
+            constexpr int LO1 = TileRound<LT, I + 1>::LO, R1 = TileRound<LT, I + 1>::R;
+            const uint32_t base1 = lane_base<LO1, R1>(t);
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k) v[k] = elem_from_bits<A>(lds[lds_slot(base1 | reg_offset<LO1, R1>(k))]);
+        }
+    });
 
     // coalesced write-out: lane t stores tile indices t + 256 k
+    uint64_t out[kRegs];
 #pragma unroll
     for (int k = 0; k < kRegs; ++k) {
-        const uint32_t idx = t + (uint32_t)k * kThreads;
-        const size_t gi = tile_base + idx;
-        const uint64_t bits = lds[lds_slot(idx)];
-        if (gi < total) data[gi] = RAW_OUT ? bits : A::store_canonical(elem_from_bits<A>(bits), p);
+        const uint64_t bits = lds[lds_slot(t + (uint32_t)k * kThreads)];
+        out[k] = RAW_OUT ? bits : A::store_canonical(elem_from_bits<A>(bits), p);
+    }
+    if (full_tile) {
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k) data[tile_base + t + (size_t)k * kThreads] = out[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k) {
+            const size_t gi = tile_base + t + (size_t)k * kThreads;
+            if (gi < total) data[gi] = out[k];
+        }
     }
 }
 
@@ -164,53 +232,74 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
                                                                const typename A::twid* __restrict__ tw, RoundConsts<A> cs) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
+    using twid = typename A::twid;
+    constexpr int NR = TileRound<LT, 0>::kCount;
     const uint32_t t = threadIdx.x;
     const size_t tile_base = (size_t)blockIdx.x * kTile;
     const uint32_t nmask = (1u << p.logn) - 1u;
     const uint32_t block_pos = (uint32_t)(tile_base & nmask);
+    const bool full_tile = tile_base + kTile <= total;   // block-uniform
     elem v[kRegs];
+    twid w[2][kRoundTwiddles];
 
-    // coalesced read-in to LDS (raw element bits)
+    {   // coalesced read-in to LDS (raw element bits); the first round's twiddles ride along
+        uint64_t raw[kRegs];
+        if (full_tile) {
 #pragma unroll
-    for (int k = 0; k < kRegs; ++k) {
-        const uint32_t idx = t + (uint32_t)k * kThreads;
-        const size_t gi = tile_base + idx;
-        const uint64_t raw = gi < total ? data[gi] : 0;
-        lds[lds_slot(idx)] = RAW_IN ? raw : elem_bits<A>(A::load(raw, p));
+            for (int k = 0; k < kRegs; ++k) raw[k] = data[tile_base + t + (size_t)k * kThreads];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k) {
+                const size_t gi = tile_base + t + (size_t)k * kThreads;
+                raw[k] = gi < total ? data[gi] : 0;
+            }
+        }
+        constexpr int J = NR - 1;
+        constexpr int LO = TileRound<LT, J>::LO, R = TileRound<LT, J>::R;
+        load_round_twiddles<A, LO, R, true, (NR == 1) && !RAW_OUT>(w[0], lane_base<LO, R>(t), block_pos, nmask, p.logn, tw);
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k) lds[lds_slot(t + (uint32_t)k * kThreads)] = RAW_IN ? raw[k] : elem_bits<A>(A::load(raw[k], p));
     }
     __syncthreads();
 
-    auto run_round = [&](auto lo_tag, auto r_tag, bool last) {
-        constexpr int LO = decltype(lo_tag)::value;
-        constexpr int R = decltype(r_tag)::value;
+    static_for<0, NR>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;          // I-th inverse round = forward round NR-1-I
+        constexpr int J = NR - 1 - I;
+        constexpr int LO = TileRound<LT, J>::LO, R = TileRound<LT, J>::R;
+        constexpr bool kLast = (I == NR - 1);
+        constexpr bool kFinal = kLast && !RAW_OUT;      // outputs of the n^-1-scaled stage (LT == log n)
         const uint32_t base = lane_base<LO, R>(t);
 #pragma unroll
         for (int k = 0; k < kRegs; ++k) v[k] = elem_from_bits<A>(lds[lds_slot(base | reg_offset<LO, R>(k))]);
-        inverse_round<A, LO, R>(v, base, block_pos, nmask, p, tw, cs);
-        const bool final_values = last && (LT == p.logn);   // these are outputs of the n^-1-scaled stage
-        if (!final_values) {
+        if constexpr (!kLast) {
+            constexpr int J1 = J - 1;
+            constexpr int LO1 = TileRound<LT, J1>::LO, R1 = TileRound<LT, J1>::R;
+            constexpr bool kNextFinal = (I + 1 == NR - 1) && !RAW_OUT;
+            load_round_twiddles<A, LO1, R1, true, kNextFinal>(w[(I + 1) & 1], lane_base<LO1, R1>(t), block_pos, nmask, p.logn, tw);
+        }
+        inverse_round<A, LO, R, kFinal>(v, w[I & 1], p, cs);
+        if constexpr (!kFinal) {
 #pragma unroll
             for (int k = 0; k < kRegs; ++k) A::end_of_inverse_round(v[k], p);
         }
-        if (last) {
+        if constexpr (kLast) {
+            if (full_tile) {
 #pragma unroll
-            for (int k = 0; k < kRegs; ++k) {
-                const size_t gi = tile_base + (base | reg_offset<LO, R>(k));
-                if (gi < total) data[gi] = RAW_OUT ? elem_bits<A>(v[k]) : A::store_reduced(v[k], p);
+                for (int k = 0; k < kRegs; ++k)
+                    data[tile_base + (base | reg_offset<LO, R>(k))] = RAW_OUT ? elem_bits<A>(v[k]) : A::store_reduced(v[k], p);
+            } else {
+#pragma unroll
+                for (int k = 0; k < kRegs; ++k) {
+                    const size_t gi = tile_base + (base | reg_offset<LO, R>(k));
+                    if (gi < total) data[gi] = RAW_OUT ? elem_bits<A>(v[k]) : A::store_reduced(v[k], p);
+                }
             }
         } else {
 #pragma unroll
             for (int k = 0; k < kRegs; ++k) lds[lds_slot(base | reg_offset<LO, R>(k))] = elem_bits<A>(v[k]);
             __syncthreads();
         }
-    };
-
-    constexpr int REM = LT % 4;
-    constexpr int FULL = LT / 4;
-    if constexpr (REM > 0) run_round(std::integral_constant<int, 0>{}, std::integral_constant<int, REM>{}, FULL == 0);
-    if constexpr (FULL >= 1) run_round(std::integral_constant<int, REM>{}, std::integral_constant<int, 4>{}, FULL == 1);
-    if constexpr (FULL >= 2) run_round(std::integral_constant<int, REM + 4>{}, std::integral_constant<int, 4>{}, FULL == 2);
-    if constexpr (FULL >= 3) run_round(std::integral_constant<int, REM + 8>{}, std::integral_constant<int, 4>{}, FULL == 3);
+    });
 }
 
 // ---- strided round kernel (index bits [lo, lo+R), lo >= 12) ----------------------------------------
@@ -252,7 +341,11 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
         for (int j = 0; j < R; ++j) {
             const int b = lo + j;
             const int half = 1 << j;
-            const bool last_stage = (b == p.logn - 1);
+            if (!RAW_OUT && j == R - 1) {   // the transform's last stage (bit log n - 1)
+#pragma unroll
+                for (int l = 0; l < half; ++l) A::gs_scaled(v[l], v[l + half], cs.w_last_scaled, cs.n_inv, p);
+                continue;
+            }
             const uint32_t tw_base = (1u << (p.logn - 1 - b)) + (pos0 >> (b + 1));
 #pragma unroll
             for (int u = 0; u < (1 << (R - 1 - j)); ++u) {
@@ -260,12 +353,11 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
 #pragma unroll
                 for (int l = 0; l < half; ++l) {
                     const int kx = (u << (j + 1)) | l;
-                    if (last_stage) A::gs_scaled(v[kx], v[kx + half], cs.w_last_scaled, cs.n_inv, p);
-                    else A::gs(v[kx], v[kx + half], w, p);
+                    A::gs(v[kx], v[kx + half], w, p);
                 }
             }
         }
-        if (lo + R != p.logn) {
+        if (RAW_OUT) {
 #pragma unroll
             for (int k = 0; k < N; ++k) A::end_of_inverse_round(v[k], p);
         }
@@ -281,7 +373,7 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
 
 // ---- pointwise product (ntt.cpp:106-119) ------------------------------------------------------------
 static __global__ void __launch_bounds__(kThreads) pointwise_mul_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ a,
-                                                                   const uint64_t* __restrict__ b, size_t count, ModParams p) {
+                                                                          const uint64_t* __restrict__ b, size_t count, ModParams p) {
     const size_t stride = (size_t)gridDim.x * kThreads;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += stride) out[i] = mulmod_barrett128(a[i], b[i], p);
 }
