@@ -61,6 +61,16 @@ def cpu_baseline(sample_polys):
             "sample": f"{done} polys x (fwd+inv), n=2^16, q={Q16}, single thread, {dt:.1f} s"}
 
 
+def measured_traffic_per_forward_transform():
+    """HBM-side bytes per forward transform from the committed PMC passes of the latest round (profiles/), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_inputs.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get("forward_bytes_per_transform")
+
+
 def main():
     args = parse()
     import torch
@@ -175,8 +185,12 @@ def main():
             "dtype": "u64 residues (exact f64-FMA Barrett arithmetic)" if ctx.uses_f64 else "u64", "data": "synthetic",
             "config": {"workload": "config2: batched forward+inverse negacyclic NTT, n=2^16, 4096 polys/GPU, q=17592182243329 (44-bit)",
                        "polys_per_gpu": args.polys, "ring_degree": N, "modulus": Q16, "parallelism": f"independent batches x{world}, no collectives"},
+            # achieved = ALGORITHMIC bytes (1 MiB per transform) / measured time of one forward batch launch sequence
+            # (8 chunks x {ntt_strided_round<4>, ntt_tile_forward<12>}); traffic = PMC bytes of the same sequence.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "forward NTT batch (strided round + tile kernel), 1 MiB algorithmic bytes per transform"},
+                         "traffic": (measured_traffic_per_forward_transform() or 0) * args.polys or None,
+                         "algorithmic_bytes": NTT_BYTES * args.polys, "launch_ms": t_fwd * 1e3,
+                         "kernel": "forward NTT batch = ntt_strided_round<ArithF64,4> + ntt_tile_forward<ArithF64,12> per 512-poly chunk"},
             "extra": extra,
         }
         if not args.no_cpu:

@@ -58,6 +58,33 @@ __device__ __forceinline__ double canonical_f64(double v, double q, double inv_q
     return r < 0.0 ? r + q : r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// buffer-resource addressing: base in SGPRs, one 32-bit lane offset, compile-time offsets in the scalar
+// operand — no per-access VALU address arithmetic, and out-of-range lanes are dropped by the hardware.
+// ---------------------------------------------------------------------------------------------
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint64_t buf_load64(rsrc_t r, uint32_t lane_bytes, uint32_t const_bytes) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_bytes, (int)const_bytes, 0);
+    return ((uint64_t)v.y << 32) | v.x;
+}
+__device__ __forceinline__ void buf_load128(rsrc_t r, uint32_t lane_bytes, uint32_t const_bytes, uint64_t& a, uint64_t& b) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)const_bytes, 0);
+    a = ((uint64_t)v.y << 32) | v.x;
+    b = ((uint64_t)v.w << 32) | v.z;
+}
+__device__ __forceinline__ void buf_store64(rsrc_t r, uint32_t lane_bytes, uint32_t const_bytes, uint64_t x) {
+    u32x2 v;
+    v.x = (uint32_t)x;
+    v.y = (uint32_t)(x >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)lane_bytes, (int)const_bytes, 0);
+}
+
 struct ArithF64 {
     using elem = double;     // residue (exact integer in a double)
     using twid = double;     // twiddle (canonical, as double)
@@ -75,7 +102,28 @@ struct ArithF64 {
     static __device__ __forceinline__ uint64_t store_reduced(elem v, const ModParams& p) {
         return u52_from_f64(v < 0.0 ? v + p.qd : v);
     }
+    // canonical (v + e) mod q for |v| < q and a canonical residue e (the fused blinding add)
+    static __device__ __forceinline__ uint64_t store_reduced_plus(elem v, uint64_t e, const ModParams& p) {
+        double s = (v < 0.0 ? v + p.qd : v) + f64_from_u52(e);
+        s = s >= p.qd ? s - p.qd : s;
+        return u52_from_f64(s);
+    }
     static __device__ __forceinline__ twid load_tw(const double* table, uint32_t idx) { return table[idx]; }
+    // COUNT consecutive table entries starting at idx (COUNT a power of two, idx a multiple of COUNT)
+    template <int COUNT>
+    static __device__ __forceinline__ void load_tw_run(rsrc_t table, uint32_t idx, twid* out) {
+        if constexpr (COUNT == 1) {
+            out[0] = __longlong_as_double((long long)buf_load64(table, idx * 8u, 0));
+        } else {
+#pragma unroll
+            for (int u = 0; u < COUNT; u += 2) {
+                uint64_t a, b;
+                buf_load128(table, idx * 8u, (uint32_t)u * 8u, a, b);
+                out[u] = __longlong_as_double((long long)a);
+                out[u + 1] = __longlong_as_double((long long)b);
+            }
+        }
+    }
 
     // Cooley–Tukey: (x, y) <- (x + w y, x - w y)
     static __device__ __forceinline__ void ct(elem& x, elem& y, twid w, const ModParams& p) {
@@ -127,7 +175,16 @@ struct ArithU64 {
         return v;
     }
     static __device__ __forceinline__ uint64_t store_reduced(elem v, const ModParams& p) { return v >= p.q ? v - p.q : v; }
+    static __device__ __forceinline__ uint64_t store_reduced_plus(elem v, uint64_t e, const ModParams& p) {
+        uint64_t s = (v >= p.q ? v - p.q : v) + e;
+        return s >= p.q ? s - p.q : s;
+    }
     static __device__ __forceinline__ twid load_tw(const ShoupOperand* table, uint32_t idx) { return table[idx]; }
+    template <int COUNT>
+    static __device__ __forceinline__ void load_tw_run(rsrc_t table, uint32_t idx, twid* out) {
+#pragma unroll
+        for (int u = 0; u < COUNT; ++u) buf_load128(table, idx * 16u, (uint32_t)u * 16u, out[u].w, out[u].wq);
+    }
 
     static __device__ __forceinline__ void ct(elem& x, elem& y, twid w, const ModParams& p) {
         const uint64_t u = x >= p.two_q ? x - p.two_q : x;

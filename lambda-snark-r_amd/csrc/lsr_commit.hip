@@ -62,6 +62,55 @@ __global__ void __launch_bounds__(256) matvec_kernel(uint64_t* __restrict__ out,
     out[gid] = result;
 }
 
+// Rank-specialised form for the commitment's square product: one lane owns residue x of one witness vector and
+// produces all K outputs  out[j][c] = sum_i M[i*K + c] * vec[j][i]  (TRANSPOSED = A^T r, the commit) or
+// out[j][c] = sum_i M[c*K + i] * vec[j][i] (+ add[c]) (A s + e, key generation), loading vec once.
+template <int K, bool F64, bool TRANSPOSED>
+__global__ void __launch_bounds__(256) matvec_square_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ mat, const uint64_t* __restrict__ vec,
+                                                              const uint64_t* __restrict__ add, uint32_t logn, uint64_t batch, ModParams p) {
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t n = 1ull << logn;
+    if (gid >= batch * n) return;
+    const uint64_t x = gid & (n - 1);
+    const uint64_t j = gid >> logn;
+    const uint64_t* v = vec + (j * K) * n + x;
+    uint64_t* o = out + (j * K) * n + x;
+    if (F64) {
+        double r[K], acc[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) r[i] = f64_from_u52(v[(uint64_t)i * n]);
+#pragma unroll
+        for (int c = 0; c < K; ++c) acc[c] = add ? f64_from_u52(add[(uint64_t)c * n + x]) : 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                const uint64_t m = mat[(uint64_t)(TRANSPOSED ? i * K + c : c * K + i) * n + x];
+                acc[c] += mulmod_f64(f64_from_u52(m), r[i], p.qd, p.inv_qd);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < K; ++c) o[(uint64_t)c * n] = u52_from_f64(canonical_f64(acc[c], p.qd, p.inv_qd));
+    } else {
+        uint64_t r[K], acc[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) r[i] = v[(uint64_t)i * n];
+#pragma unroll
+        for (int c = 0; c < K; ++c) acc[c] = add ? add[(uint64_t)c * n + x] : 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                const uint64_t m = mat[(uint64_t)(TRANSPOSED ? i * K + c : c * K + i) * n + x];
+                acc[c] += mulmod_barrett128(m, r[i], p);
+                if (acc[c] >= p.q) acc[c] -= p.q;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < K; ++c) o[(uint64_t)c * n] = acc[c];
+    }
+}
+
 // dst = (dst + a (+ b)) mod q, all canonical
 __global__ void __launch_bounds__(256) add_mod_kernel(uint64_t* __restrict__ dst, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
                                                         uint64_t count, uint64_t q) {
@@ -168,6 +217,36 @@ static void matvec(const LweContext& c, uint64_t* out, const uint64_t* mat, cons
     LSR_HIP(hipGetLastError());
 }
 
+// out[j] = M^(T) vec[j] (+ add) for the k x k matrix; rank-specialised kernels for k <= 4, generic otherwise
+template <int K>
+static void launch_square(const LweContext& c, uint64_t* out, const uint64_t* mat, const uint64_t* vec, const uint64_t* add, bool transposed,
+                          uint64_t batch, hipStream_t s) {
+    const unsigned grid = static_cast<unsigned>((batch * c.n + 255) / 256);
+    const uint32_t logn = static_cast<uint32_t>(c.logn);
+    if (c.ntt->use_f64) {
+        if (transposed) hipLaunchKernelGGL((matvec_square_kernel<K, true, true>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
+        else hipLaunchKernelGGL((matvec_square_kernel<K, true, false>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
+    } else {
+        if (transposed) hipLaunchKernelGGL((matvec_square_kernel<K, false, true>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
+        else hipLaunchKernelGGL((matvec_square_kernel<K, false, false>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
+    }
+    LSR_HIP(hipGetLastError());
+}
+
+static void matvec_square(const LweContext& c, uint64_t* out, const uint64_t* mat, const uint64_t* vec, const uint64_t* add, bool transposed,
+                          uint64_t batch, hipStream_t s) {
+    if (!batch) return;
+    switch (c.k) {
+        case 1: launch_square<1>(c, out, mat, vec, add, transposed, batch, s); break;
+        case 2: launch_square<2>(c, out, mat, vec, add, transposed, batch, s); break;
+        case 3: launch_square<3>(c, out, mat, vec, add, transposed, batch, s); break;
+        case 4: launch_square<4>(c, out, mat, vec, add, transposed, batch, s); break;
+        default:
+            if (transposed) matvec(c, out, mat, vec, add, c.k, c.k, 1, c.k, batch, s);
+            else matvec(c, out, mat, vec, add, c.k, c.k, c.k, 1, batch, s);
+    }
+}
+
 static void ensure_workspace(const LweContext& c, size_t batch) {
     if (batch <= c.ws_batch) return;
     const size_t kn = (size_t)c.k * c.n;
@@ -227,7 +306,7 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
         launch_ntt(*c->ntt, c->s_hat.ptr, k, false, s);
         launch_ntt(*c->ntt, e_hat.ptr, k, false, s);
         // b_hat[i] = sum_j A_hat[i][j] s_hat[j] + e_hat[i]
-        matvec(*c, c->b_hat.ptr, c->a_hat.ptr, c->s_hat.ptr, e_hat.ptr, k, k, k, 1, 1, s);
+        matvec_square(*c, c->b_hat.ptr, c->a_hat.ptr, c->s_hat.ptr, e_hat.ptr, false, 1, s);
         LSR_HIP(hipStreamSynchronize(s));
     } catch (const std::exception& e) {
         set_last_error(std::string("lwe_context_create: ") + e.what());
@@ -257,14 +336,10 @@ static void destroy_lwe_context(LweContext* c) {
 static void mlwe_matvec_device(const LweContext& c, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s) {
     const uint32_t k = c.k;
     launch_ntt(*c.ntt, d_r, batch * k, false, s);
-    // u[j][col] = sum_i A_hat[i][col] r_hat[j][i]  -> "rows" = col, M[row*1 + i*k]
-    matvec(c, d_u, c.a_hat.ptr, d_r, nullptr, k, k, 1, k, batch, s);
-    launch_ntt(*c.ntt, d_u, batch * k, true, s);
-    if (d_e1) {
-        const uint64_t count = (uint64_t)batch * k * c.n;
-        hipLaunchKernelGGL(add_mod_kernel, dim3(grid_for(count)), dim3(256), 0, s, d_u, d_e1, (const uint64_t*)nullptr, count, c.q);
-        LSR_HIP(hipGetLastError());
-    }
+    // u[j][col] = sum_i A_hat[i][col] r_hat[j][i]
+    matvec_square(c, d_u, c.a_hat.ptr, d_r, nullptr, true, batch, s);
+    // inverse transform with the blinding add fused into its final store
+    launch_ntt(*c.ntt, d_u, batch * k, true, s, d_e1);
 }
 
 static LweCommitment* new_commitment(size_t words) {

@@ -171,29 +171,40 @@ template <> struct Flavour<ArithU64> {
     static RoundConsts<ArithU64> consts(const NttContext& c) { return {c.n_inv_u64, c.w_last_scaled_u64}; }
 };
 
+// log2(blocks per polynomial) for the XCD-affine block mapping of the two-pass transforms, or -1 (identity)
+static int affine_bpp_log(const NttContext& c, int blocks_log) {
+    static const bool on = [] {
+        const char* e = std::getenv("LAMBDA_SNARK_NTT_XCD_AFFINE");
+        return e && e[0] == '1';
+    }();
+    return (on && c.logn > kTileLog) ? blocks_log : -1;
+}
+
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 static void tile_fwd(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
     const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
-    hipLaunchKernelGGL((ntt_tile_forward<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::fwd(c));
+    hipLaunchKernelGGL((ntt_tile_forward<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::fwd(c),
+                       affine_bpp_log(c, c.logn - kTileLog));
 }
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
-static void tile_inv(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
+static void tile_inv(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* add = nullptr) {
     const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
     hipLaunchKernelGGL((ntt_tile_inverse<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::inv(c),
-                       Flavour<A>::consts(c));
+                       Flavour<A>::consts(c), add, affine_bpp_log(c, c.logn - kTileLog));
 }
 
 template <class A, bool INVERSE, bool RAW_IN, bool RAW_OUT>
-static void strided(const NttContext& c, uint64_t* d, size_t total, int lo, int r, hipStream_t s) {
+static void strided(const NttContext& c, uint64_t* d, size_t total, int lo, int r, hipStream_t s, const uint64_t* add = nullptr) {
     const size_t groups = total >> r;
     const unsigned grid = static_cast<unsigned>((groups + kThreads - 1) / kThreads);
     const auto* tw = INVERSE ? Flavour<A>::inv(c) : Flavour<A>::fwd(c);
     const auto cs = Flavour<A>::consts(c);
+    const int bpp = affine_bpp_log(c, c.logn - r - 8);   // a polynomial is 2^(logn-r) groups = 2^(logn-r-8) blocks
     switch (r) {
-        case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs); break;
-        case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs); break;
-        case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs); break;
-        default: hipLaunchKernelGGL((ntt_strided_round<A, 4, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs); break;
+        case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        default: hipLaunchKernelGGL((ntt_strided_round<A, 4, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
     }
 }
 
@@ -215,20 +226,20 @@ static void small_forward(const NttContext& c, uint64_t* d, size_t total, hipStr
     }
 }
 template <class A>
-static void small_inverse(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
+static void small_inverse(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* add) {
     switch (c.logn) {
-        case 1: tile_inv<A, 1, false, false>(c, d, total, s); break;
-        case 2: tile_inv<A, 2, false, false>(c, d, total, s); break;
-        case 3: tile_inv<A, 3, false, false>(c, d, total, s); break;
-        case 4: tile_inv<A, 4, false, false>(c, d, total, s); break;
-        case 5: tile_inv<A, 5, false, false>(c, d, total, s); break;
-        case 6: tile_inv<A, 6, false, false>(c, d, total, s); break;
-        case 7: tile_inv<A, 7, false, false>(c, d, total, s); break;
-        case 8: tile_inv<A, 8, false, false>(c, d, total, s); break;
-        case 9: tile_inv<A, 9, false, false>(c, d, total, s); break;
-        case 10: tile_inv<A, 10, false, false>(c, d, total, s); break;
-        case 11: tile_inv<A, 11, false, false>(c, d, total, s); break;
-        default: tile_inv<A, 12, false, false>(c, d, total, s); break;
+        case 1: tile_inv<A, 1, false, false>(c, d, total, s, add); break;
+        case 2: tile_inv<A, 2, false, false>(c, d, total, s, add); break;
+        case 3: tile_inv<A, 3, false, false>(c, d, total, s, add); break;
+        case 4: tile_inv<A, 4, false, false>(c, d, total, s, add); break;
+        case 5: tile_inv<A, 5, false, false>(c, d, total, s, add); break;
+        case 6: tile_inv<A, 6, false, false>(c, d, total, s, add); break;
+        case 7: tile_inv<A, 7, false, false>(c, d, total, s, add); break;
+        case 8: tile_inv<A, 8, false, false>(c, d, total, s, add); break;
+        case 9: tile_inv<A, 9, false, false>(c, d, total, s, add); break;
+        case 10: tile_inv<A, 10, false, false>(c, d, total, s, add); break;
+        case 11: tile_inv<A, 11, false, false>(c, d, total, s, add); break;
+        default: tile_inv<A, 12, false, false>(c, d, total, s, add); break;
     }
 }
 
@@ -238,7 +249,7 @@ static size_t ntt_chunk_bytes() {
             const long v = std::atol(e);
             if (v > 0) return static_cast<size_t>(v) << 20;
         }
-        return static_cast<size_t>(64) << 20;
+        return static_cast<size_t>(256) << 20;
     }();
     return bytes;
 }
@@ -246,17 +257,17 @@ static size_t ntt_chunk_bytes() {
 static bool ntt_overlap_enabled() {
     static const bool on = [] {
         const char* e = std::getenv("LAMBDA_SNARK_NTT_OVERLAP");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';   // measured: no gain once the fabric is the limiter (profiles/r01_chunk_sweep.txt)
     }();
     return on;
 }
 
 template <class A>
-static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s) {
+static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s, const uint64_t* add) {
     const size_t total = batch << c.logn;
     if (total == 0) return;
     if (c.logn <= kTileLog) {
-        if (inverse) small_inverse<A>(c, d, total, s);
+        if (inverse) small_inverse<A>(c, d, total, s, add);
         else small_forward<A>(c, d, total, s);
         return;
     }
@@ -286,7 +297,7 @@ static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse
         } else {
             tile_inv<A, 12, false, true>(c, base, count, cs);
             if (r_low) strided<A, true, true, true>(c, base, count, kTileLog, r_low, cs);
-            strided<A, true, true, false>(c, base, count, c.logn - r_top, r_top, cs);
+            strided<A, true, true, false>(c, base, count, c.logn - r_top, r_top, cs, add ? add + (first << c.logn) : nullptr);
         }
     }
     if (overlap) {
@@ -297,9 +308,9 @@ static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse
     }
 }
 
-void launch_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s) {
-    if (c.use_f64) run_ntt<ArithF64>(c, d, batch, inverse, s);
-    else run_ntt<ArithU64>(c, d, batch, inverse, s);
+void launch_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s, const uint64_t* add_on_inverse) {
+    if (c.use_f64) run_ntt<ArithF64>(c, d, batch, inverse, s, inverse ? add_on_inverse : nullptr);
+    else run_ntt<ArithU64>(c, d, batch, inverse, s, inverse ? add_on_inverse : nullptr);
     LSR_HIP(hipGetLastError());
 }
 

@@ -37,7 +37,9 @@ struct RoundConsts {
     typename A::twid w_last_scaled;  // inverse twiddle of the last GS stage times n^-1
 };
 
-__device__ __forceinline__ uint32_t lds_slot(uint32_t idx) { return idx + (idx >> 4); }
+// padded LDS slot of tile index idx.  For idx = lane part | constant part with disjoint bits the slot splits into
+// lds_slot(lane) + lds_slot(constant), so every access is one lane address plus an immediate offset.
+__host__ __device__ constexpr uint32_t lds_slot(uint32_t idx) { return idx + (idx >> 4); }
 
 template <class A> __device__ __forceinline__ uint64_t elem_bits(typename A::elem v);
 template <> __device__ __forceinline__ uint64_t elem_bits<ArithF64>(double v) { return (uint64_t)__double_as_longlong(v); }
@@ -81,20 +83,23 @@ __host__ __device__ constexpr uint32_t reg_offset(int k) {
 // SKIP_TOP: the stage of bit LO+R-1 takes its multipliers from RoundConsts (last inverse stage).
 template <class A, int LO, int R, bool INVERSE, bool SKIP_TOP>
 __device__ __forceinline__ void load_round_twiddles(typename A::twid (&w)[kRoundTwiddles], uint32_t base_idx, uint32_t block_pos,
-                                                    uint32_t nmask, int logn, const typename A::twid* __restrict__ tw) {
+                                                    uint32_t nmask, int logn, rsrc_t tw) {
     constexpr int G = 1 << (4 - R);
-    int slot = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const uint32_t pos0 = (block_pos + (base_idx | ((uint32_t)g << (8 + R)))) & nmask;
-#pragma unroll
-        for (int step = 0; step < R; ++step) {
-            const int b = INVERSE ? LO + step : LO + R - 1 - step;
-            if (SKIP_TOP && b == LO + R - 1) continue;
-            const uint32_t tw_base = (1u << (logn - 1 - b)) + (pos0 >> (b + 1));
-#pragma unroll
-            for (int u = 0; u < (1 << (LO + R - 1 - b)); ++u) w[slot++] = A::load_tw(tw, tw_base + u);
-        }
+        static_for<0, R>([&](auto sc) {
+            constexpr int step = decltype(sc)::value;
+            constexpr int b = INVERSE ? LO + step : LO + R - 1 - step;
+            if constexpr (!(SKIP_TOP && b == LO + R - 1)) {
+                constexpr int count = 1 << (LO + R - 1 - b);
+                // slots before this run: earlier groups, then earlier stages of this group
+                constexpr int per_group = (1 << R) - 1 - (SKIP_TOP ? 1 : 0);
+                constexpr int before = INVERSE ? ((1 << R) - (1 << (R - step))) : ((1 << step) - 1) - (SKIP_TOP && step > 0 ? 1 : 0);
+                const uint32_t tw_base = (1u << (logn - 1 - b)) + (pos0 >> (b + 1));
+                A::template load_tw_run<count>(tw, tw_base, &w[g * per_group + before]);
+            }
+        });
     }
 }
 
@@ -151,21 +156,40 @@ __device__ __forceinline__ void inverse_round(typename A::elem (&v)[kRegs], cons
     }
 }
 
+// XCD-affine virtual block index.  The dispatcher deals workgroups round-robin over the 8 XCDs (block b -> XCD b % 8,
+// observed, speed only).  With `bpp_log` = log2(blocks per polynomial) >= 0 and a grid that is a multiple of
+// 8 << bpp_log, polynomial p's blocks are given hardware indices congruent to p mod 8, so that both passes of a
+// two-pass transform touch p through the same XCD's L2.  bpp_log < 0: identity.
+__device__ __forceinline__ uint32_t virtual_block(uint32_t b, int bpp_log, uint32_t grid) {
+    if (bpp_log < 0) return b;
+    const uint32_t span = 8u << bpp_log;
+    const uint32_t full = grid - (grid % span);
+    if (b >= full) return b;
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    const uint32_t poly = ((slot >> bpp_log) << 3) | xcd;
+    return (poly << bpp_log) | (slot & ((1u << bpp_log) - 1u));
+}
+
 // ---- tile kernel -----------------------------------------------------------------------------------
 // LT = number of low index bits this kernel transforms (min(L,12)).  RAW_IN / RAW_OUT: the global array
 // holds raw element bit patterns (pass boundary of a two-pass transform) instead of canonical uint64.
+// Global and twiddle accesses go through buffer resources: the tile's base sits in SGPRs, each lane carries
+// one byte offset per mapping, register offsets are immediates, and a partial last tile is clipped by the
+// resource's size (loads return 0, stores are dropped).
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restrict__ data, size_t total, ModParams p,
-                                                               const typename A::twid* __restrict__ tw) {
+                                                               const typename A::twid* __restrict__ tw, int bpp_log) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
     using twid = typename A::twid;
     constexpr int NR = TileRound<LT, 0>::kCount;
     const uint32_t t = threadIdx.x;
-    const size_t tile_base = (size_t)blockIdx.x * kTile;
+    const size_t tile_base = (size_t)virtual_block(blockIdx.x, bpp_log, gridDim.x) * kTile;
     const uint32_t nmask = (1u << p.logn) - 1u;
     const uint32_t block_pos = (uint32_t)(tile_base & nmask);
-    const bool full_tile = tile_base + kTile <= total;   // block-uniform
+    const size_t left = total - tile_base;
+    const rsrc_t tile = make_rsrc(data + tile_base, left >= kTile ? kTile * 8u : (uint32_t)left * 8u);
+    const rsrc_t table = make_rsrc(tw, (uint32_t)sizeof(twid) << p.logn);
     elem v[kRegs];
     twid w[2][kRoundTwiddles];
 
@@ -173,17 +197,9 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restric
         constexpr int LO = TileRound<LT, 0>::LO, R = TileRound<LT, 0>::R;
         const uint32_t base = lane_base<LO, R>(t);
         uint64_t raw[kRegs];
-        if (full_tile) {
 #pragma unroll
-            for (int k = 0; k < kRegs; ++k) raw[k] = data[tile_base + (base | reg_offset<LO, R>(k))];
-        } else {
-#pragma unroll
-            for (int k = 0; k < kRegs; ++k) {
-                const size_t gi = tile_base + (base | reg_offset<LO, R>(k));
-                raw[k] = gi < total ? data[gi] : 0;
-            }
-        }
-        load_round_twiddles<A, LO, R, false, false>(w[0], base, block_pos, nmask, p.logn, tw);
+        for (int k = 0; k < kRegs; ++k) raw[k] = buf_load64(tile, base * 8u, reg_offset<LO, R>(k) * 8u);
+        load_round_twiddles<A, LO, R, false, false>(w[0], base, block_pos, nmask, p.logn, table);
 #pragma unroll
         for (int k = 0; k < kRegs; ++k) v[k] = RAW_IN ? elem_from_bits<A>(raw[k]) : A::load(raw[k], p);
     }
@@ -194,71 +210,61 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restric
         const uint32_t base = lane_base<LO, R>(t);
         if constexpr (I + 1 < NR) {   // request the next round's twiddles before this round's arithmetic
             constexpr int LO1 = TileRound<LT, I + 1>::LO, R1 = TileRound<LT, I + 1>::R;
-            load_round_twiddles<A, LO1, R1, false, false>(w[(I + 1) & 1], lane_base<LO1, R1>(t), block_pos, nmask, p.logn, tw);
+            load_round_twiddles<A, LO1, R1, false, false>(w[(I + 1) & 1], lane_base<LO1, R1>(t), block_pos, nmask, p.logn, table);
         }
         forward_round<A, LO, R>(v, w[I & 1], p);
+        uint64_t* const row = lds + lds_slot(base);
 #pragma unroll
-        for (int k = 0; k < kRegs; ++k) lds[lds_slot(base | reg_offset<LO, R>(k))] = elem_bits<A>(v[k]);
+        for (int k = 0; k < kRegs; ++k) row[lds_slot(reg_offset<LO, R>(k))] = elem_bits<A>(v[k]);
         __syncthreads();
         if constexpr (I + 1 < NR) {
             constexpr int LO1 = TileRound<LT, I + 1>::LO, R1 = TileRound<LT, I + 1>::R;
-            const uint32_t base1 = lane_base<LO1, R1>(t);
+            const uint64_t* const row1 = lds + lds_slot(lane_base<LO1, R1>(t));
 #pragma unroll
-            for (int k = 0; k < kRegs; ++k) v[k] = elem_from_bits<A>(lds[lds_slot(base1 | reg_offset<LO1, R1>(k))]);
+            for (int k = 0; k < kRegs; ++k) v[k] = elem_from_bits<A>(row1[lds_slot(reg_offset<LO1, R1>(k))]);
         }
     });
 
     // coalesced write-out: lane t stores tile indices t + 256 k
-    uint64_t out[kRegs];
+    const uint64_t* const col = lds + lds_slot(t);
 #pragma unroll
     for (int k = 0; k < kRegs; ++k) {
-        const uint64_t bits = lds[lds_slot(t + (uint32_t)k * kThreads)];
-        out[k] = RAW_OUT ? bits : A::store_canonical(elem_from_bits<A>(bits), p);
-    }
-    if (full_tile) {
-#pragma unroll
-        for (int k = 0; k < kRegs; ++k) data[tile_base + t + (size_t)k * kThreads] = out[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < kRegs; ++k) {
-            const size_t gi = tile_base + t + (size_t)k * kThreads;
-            if (gi < total) data[gi] = out[k];
-        }
+        const uint64_t bits = col[lds_slot((uint32_t)k * kThreads)];
+        buf_store64(tile, t * 8u, (uint32_t)k * kThreads * 8u, RAW_OUT ? bits : A::store_canonical(elem_from_bits<A>(bits), p));
     }
 }
 
+// `add` (optional, only when !RAW_OUT): canonical residues added to the outputs on the final store — the fused
+// discrete-Gaussian blinding add of the commitment (u = INTT(...) + e1).
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restrict__ data, size_t total, ModParams p,
-                                                               const typename A::twid* __restrict__ tw, RoundConsts<A> cs) {
+                                                               const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
+                                                               const uint64_t* __restrict__ add, int bpp_log) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
     using twid = typename A::twid;
     constexpr int NR = TileRound<LT, 0>::kCount;
     const uint32_t t = threadIdx.x;
-    const size_t tile_base = (size_t)blockIdx.x * kTile;
+    const size_t tile_base = (size_t)virtual_block(blockIdx.x, bpp_log, gridDim.x) * kTile;
     const uint32_t nmask = (1u << p.logn) - 1u;
     const uint32_t block_pos = (uint32_t)(tile_base & nmask);
-    const bool full_tile = tile_base + kTile <= total;   // block-uniform
+    const size_t left = total - tile_base;
+    const uint32_t tile_bytes = left >= kTile ? kTile * 8u : (uint32_t)left * 8u;
+    const rsrc_t tile = make_rsrc(data + tile_base, tile_bytes);
+    const rsrc_t table = make_rsrc(tw, (uint32_t)sizeof(twid) << p.logn);
     elem v[kRegs];
     twid w[2][kRoundTwiddles];
 
     {   // coalesced read-in to LDS (raw element bits); the first round's twiddles ride along
         uint64_t raw[kRegs];
-        if (full_tile) {
 #pragma unroll
-            for (int k = 0; k < kRegs; ++k) raw[k] = data[tile_base + t + (size_t)k * kThreads];
-        } else {
-#pragma unroll
-            for (int k = 0; k < kRegs; ++k) {
-                const size_t gi = tile_base + t + (size_t)k * kThreads;
-                raw[k] = gi < total ? data[gi] : 0;
-            }
-        }
+        for (int k = 0; k < kRegs; ++k) raw[k] = buf_load64(tile, t * 8u, (uint32_t)k * kThreads * 8u);
         constexpr int J = NR - 1;
         constexpr int LO = TileRound<LT, J>::LO, R = TileRound<LT, J>::R;
-        load_round_twiddles<A, LO, R, true, (NR == 1) && !RAW_OUT>(w[0], lane_base<LO, R>(t), block_pos, nmask, p.logn, tw);
+        load_round_twiddles<A, LO, R, true, (NR == 1) && !RAW_OUT>(w[0], lane_base<LO, R>(t), block_pos, nmask, p.logn, table);
+        uint64_t* const col = lds + lds_slot(t);
 #pragma unroll
-        for (int k = 0; k < kRegs; ++k) lds[lds_slot(t + (uint32_t)k * kThreads)] = RAW_IN ? raw[k] : elem_bits<A>(A::load(raw[k], p));
+        for (int k = 0; k < kRegs; ++k) col[lds_slot((uint32_t)k * kThreads)] = RAW_IN ? raw[k] : elem_bits<A>(A::load(raw[k], p));
     }
     __syncthreads();
 
@@ -269,13 +275,14 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
         constexpr bool kLast = (I == NR - 1);
         constexpr bool kFinal = kLast && !RAW_OUT;      // outputs of the n^-1-scaled stage (LT == log n)
         const uint32_t base = lane_base<LO, R>(t);
+        uint64_t* const row = lds + lds_slot(base);
 #pragma unroll
-        for (int k = 0; k < kRegs; ++k) v[k] = elem_from_bits<A>(lds[lds_slot(base | reg_offset<LO, R>(k))]);
+        for (int k = 0; k < kRegs; ++k) v[k] = elem_from_bits<A>(row[lds_slot(reg_offset<LO, R>(k))]);
         if constexpr (!kLast) {
             constexpr int J1 = J - 1;
             constexpr int LO1 = TileRound<LT, J1>::LO, R1 = TileRound<LT, J1>::R;
             constexpr bool kNextFinal = (I + 1 == NR - 1) && !RAW_OUT;
-            load_round_twiddles<A, LO1, R1, true, kNextFinal>(w[(I + 1) & 1], lane_base<LO1, R1>(t), block_pos, nmask, p.logn, tw);
+            load_round_twiddles<A, LO1, R1, true, kNextFinal>(w[(I + 1) & 1], lane_base<LO1, R1>(t), block_pos, nmask, p.logn, table);
         }
         inverse_round<A, LO, R, kFinal>(v, w[I & 1], p, cs);
         if constexpr (!kFinal) {
@@ -283,20 +290,21 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
             for (int k = 0; k < kRegs; ++k) A::end_of_inverse_round(v[k], p);
         }
         if constexpr (kLast) {
-            if (full_tile) {
-#pragma unroll
-                for (int k = 0; k < kRegs; ++k)
-                    data[tile_base + (base | reg_offset<LO, R>(k))] = RAW_OUT ? elem_bits<A>(v[k]) : A::store_reduced(v[k], p);
-            } else {
+            if (!RAW_OUT && add != nullptr) {
+                const rsrc_t extra = make_rsrc(add + tile_base, tile_bytes);
 #pragma unroll
                 for (int k = 0; k < kRegs; ++k) {
-                    const size_t gi = tile_base + (base | reg_offset<LO, R>(k));
-                    if (gi < total) data[gi] = RAW_OUT ? elem_bits<A>(v[k]) : A::store_reduced(v[k], p);
+                    const uint64_t e = buf_load64(extra, base * 8u, reg_offset<LO, R>(k) * 8u);
+                    buf_store64(tile, base * 8u, reg_offset<LO, R>(k) * 8u, A::store_reduced_plus(v[k], e, p));
                 }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kRegs; ++k)
+                    buf_store64(tile, base * 8u, reg_offset<LO, R>(k) * 8u, RAW_OUT ? elem_bits<A>(v[k]) : A::store_reduced(v[k], p));
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < kRegs; ++k) lds[lds_slot(base | reg_offset<LO, R>(k))] = elem_bits<A>(v[k]);
+            for (int k = 0; k < kRegs; ++k) row[lds_slot(reg_offset<LO, R>(k))] = elem_bits<A>(v[k]);
             __syncthreads();
         }
     });
@@ -305,10 +313,11 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
 // ---- strided round kernel (index bits [lo, lo+R), lo >= 12) ----------------------------------------
 template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT>
 __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
-                                                                const typename A::twid* __restrict__ tw, RoundConsts<A> cs) {
+                                                                const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
+                                                                const uint64_t* __restrict__ add, int bpp_log) {
     using elem = typename A::elem;
     constexpr int N = 1 << R;
-    const size_t group = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    const size_t group = (size_t)virtual_block(blockIdx.x, bpp_log, gridDim.x) * kThreads + threadIdx.x;
     if (group >= (total >> R)) return;
     const size_t low = group & (((size_t)1 << lo) - 1);
     const size_t idx0 = ((group >> lo) << (lo + R)) | low;
@@ -364,10 +373,12 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
+        const size_t gi = idx0 + ((size_t)k << lo);
         uint64_t out;
         if (RAW_OUT) out = elem_bits<A>(v[k]);
-        else out = INVERSE ? A::store_reduced(v[k], p) : A::store_canonical(v[k], p);
-        data[idx0 + ((size_t)k << lo)] = out;
+        else if (INVERSE) out = add != nullptr ? A::store_reduced_plus(v[k], add[gi], p) : A::store_reduced(v[k], p);
+        else out = A::store_canonical(v[k], p);
+        data[gi] = out;
     }
 }
 

@@ -103,7 +103,10 @@ namespace lsr {
 NttContext* create_ntt_context(uint64_t q, uint32_t n, int device);
 void destroy_ntt_context(NttContext* ctx);
 // asynchronous launches on `stream`, data resident on ctx->device
-void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inverse, hipStream_t stream);
+// add_on_inverse (optional): canonical residues [batch][n] added to the outputs of an inverse transform in its final
+// store (the commitment's fused blinding add)
+void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inverse, hipStream_t stream,
+                const uint64_t* add_on_inverse = nullptr);
 void launch_pointwise(const NttContext& ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t count,
                       hipStream_t stream);
 int arith_mode();
