@@ -15,6 +15,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <type_traits>
 
 #include "lambda_snark/batch.h"
 #include "lambda_snark/commitment.h"
@@ -62,52 +63,64 @@ __global__ void __launch_bounds__(256) matvec_kernel(uint64_t* __restrict__ out,
     out[gid] = result;
 }
 
-// Rank-specialised form for the commitment's square product: one lane owns residue x of one witness vector and
-// produces all K outputs  out[j][c] = sum_i M[i*K + c] * vec[j][i]  (TRANSPOSED = A^T r, the commit) or
-// out[j][c] = sum_i M[c*K + i] * vec[j][i] (+ add[c]) (A s + e, key generation), loading vec once.
-template <int K, bool F64, bool TRANSPOSED>
+// Rank-specialised form for the commitment's square product.  One lane owns residue x and walks JB consecutive
+// witness vectors with the K*K matrix residues of column x held in registers (the matrix is shared by the whole
+// batch, so its L2 traffic drops by JB):  out[j][c] = sum_i M[i*K + c] * vec[j][i]  (TRANSPOSED = A^T r, the commit)
+// or out[j][c] = sum_i M[c*K + i] * vec[j][i] (+ add[c]) (A s + e, key generation).
+template <int K, bool F64, bool TRANSPOSED, int JB>
 __global__ void __launch_bounds__(256) matvec_square_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ mat, const uint64_t* __restrict__ vec,
                                                               const uint64_t* __restrict__ add, uint32_t logn, uint64_t batch, ModParams p) {
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t n = 1ull << logn;
-    if (gid >= batch * n) return;
     const uint64_t x = gid & (n - 1);
-    const uint64_t j = gid >> logn;
-    const uint64_t* v = vec + (j * K) * n + x;
-    uint64_t* o = out + (j * K) * n + x;
-    if (F64) {
-        double r[K], acc[K];
+    const uint64_t j0 = (gid >> logn) * JB;
+    if (j0 >= batch) return;
+    using T = typename std::conditional<F64, double, uint64_t>::type;
+    T m[K][K], a[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) r[i] = f64_from_u52(v[(uint64_t)i * n]);
+    for (int i = 0; i < K; ++i)
 #pragma unroll
-        for (int c = 0; c < K; ++c) acc[c] = add ? f64_from_u52(add[(uint64_t)c * n + x]) : 0.0;
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-#pragma unroll
-            for (int c = 0; c < K; ++c) {
-                const uint64_t m = mat[(uint64_t)(TRANSPOSED ? i * K + c : c * K + i) * n + x];
-                acc[c] += mulmod_f64(f64_from_u52(m), r[i], p.qd, p.inv_qd);
-            }
+        for (int c = 0; c < K; ++c) {
+            const uint64_t raw = mat[(uint64_t)(TRANSPOSED ? i * K + c : c * K + i) * n + x];
+            if constexpr (F64) m[i][c] = f64_from_u52(raw);
+            else m[i][c] = raw;
         }
 #pragma unroll
-        for (int c = 0; c < K; ++c) o[(uint64_t)c * n] = u52_from_f64(canonical_f64(acc[c], p.qd, p.inv_qd));
-    } else {
-        uint64_t r[K], acc[K];
+    for (int c = 0; c < K; ++c) {
+        const uint64_t raw = add ? add[(uint64_t)c * n + x] : 0;
+        if constexpr (F64) a[c] = f64_from_u52(raw);
+        else a[c] = raw;
+    }
 #pragma unroll
-        for (int i = 0; i < K; ++i) r[i] = v[(uint64_t)i * n];
-#pragma unroll
-        for (int c = 0; c < K; ++c) acc[c] = add ? add[(uint64_t)c * n + x] : 0;
+    for (int jj = 0; jj < JB; ++jj) {
+        const uint64_t j = j0 + jj;
+        if (j >= batch) break;
+        const uint64_t* v = vec + (j * K) * n + x;
+        uint64_t* o = out + (j * K) * n + x;
+        T r[K], acc[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-#pragma unroll
-            for (int c = 0; c < K; ++c) {
-                const uint64_t m = mat[(uint64_t)(TRANSPOSED ? i * K + c : c * K + i) * n + x];
-                acc[c] += mulmod_barrett128(m, r[i], p);
-                if (acc[c] >= p.q) acc[c] -= p.q;
-            }
+            if constexpr (F64) r[i] = f64_from_u52(v[(uint64_t)i * n]);
+            else r[i] = v[(uint64_t)i * n];
         }
 #pragma unroll
-        for (int c = 0; c < K; ++c) o[(uint64_t)c * n] = acc[c];
+        for (int c = 0; c < K; ++c) acc[c] = a[c];
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                if constexpr (F64) {
+                    acc[c] += mulmod_f64(m[i][c], r[i], p.qd, p.inv_qd);
+                } else {
+                    acc[c] += mulmod_barrett128(m[i][c], r[i], p);
+                    if (acc[c] >= p.q) acc[c] -= p.q;
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            if constexpr (F64) o[(uint64_t)c * n] = u52_from_f64(canonical_f64(acc[c], p.qd, p.inv_qd));
+            else o[(uint64_t)c * n] = acc[c];
+        }
     }
 }
 
@@ -221,14 +234,16 @@ static void matvec(const LweContext& c, uint64_t* out, const uint64_t* mat, cons
 template <int K>
 static void launch_square(const LweContext& c, uint64_t* out, const uint64_t* mat, const uint64_t* vec, const uint64_t* add, bool transposed,
                           uint64_t batch, hipStream_t s) {
-    const unsigned grid = static_cast<unsigned>((batch * c.n + 255) / 256);
+    constexpr int JB = 4;   // witness vectors per lane
+    const uint64_t lanes = ((batch + JB - 1) / JB) * c.n;
+    const unsigned grid = static_cast<unsigned>((lanes + 255) / 256);
     const uint32_t logn = static_cast<uint32_t>(c.logn);
     if (c.ntt->use_f64) {
-        if (transposed) hipLaunchKernelGGL((matvec_square_kernel<K, true, true>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
-        else hipLaunchKernelGGL((matvec_square_kernel<K, true, false>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
+        if (transposed) hipLaunchKernelGGL((matvec_square_kernel<K, true, true, JB>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
+        else hipLaunchKernelGGL((matvec_square_kernel<K, true, false, JB>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
     } else {
-        if (transposed) hipLaunchKernelGGL((matvec_square_kernel<K, false, true>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
-        else hipLaunchKernelGGL((matvec_square_kernel<K, false, false>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
+        if (transposed) hipLaunchKernelGGL((matvec_square_kernel<K, false, true, JB>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
+        else hipLaunchKernelGGL((matvec_square_kernel<K, false, false, JB>), dim3(grid), dim3(256), 0, s, out, mat, vec, add, logn, batch, c.ntt->mod);
     }
     LSR_HIP(hipGetLastError());
 }
