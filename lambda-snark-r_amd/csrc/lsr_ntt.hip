@@ -204,7 +204,35 @@ static void strided(const NttContext& c, uint64_t* d, size_t total, int lo, int 
         case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
         case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
         case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        default: hipLaunchKernelGGL((ntt_strided_round<A, 4, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        case 4: hipLaunchKernelGGL((ntt_strided_round<A, 4, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        case 5: hipLaunchKernelGGL((ntt_strided_round<A, 5, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        default: hipLaunchKernelGGL((ntt_strided_round<A, 6, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+    }
+}
+
+// tile pass of a two-pass transform (n > 4096): LT low bits, raw element hand-off on the other side
+template <class A>
+static void pass_forward(const NttContext& c, int lt, uint64_t* d, size_t total, hipStream_t s) {
+    switch (lt) {
+        case 6: tile_fwd<A, 6, true, false>(c, d, total, s); break;
+        case 7: tile_fwd<A, 7, true, false>(c, d, total, s); break;
+        case 8: tile_fwd<A, 8, true, false>(c, d, total, s); break;
+        case 9: tile_fwd<A, 9, true, false>(c, d, total, s); break;
+        case 10: tile_fwd<A, 10, true, false>(c, d, total, s); break;
+        case 11: tile_fwd<A, 11, true, false>(c, d, total, s); break;
+        default: tile_fwd<A, 12, true, false>(c, d, total, s); break;
+    }
+}
+template <class A>
+static void pass_inverse(const NttContext& c, int lt, uint64_t* d, size_t total, hipStream_t s) {
+    switch (lt) {
+        case 6: tile_inv<A, 6, false, true>(c, d, total, s); break;
+        case 7: tile_inv<A, 7, false, true>(c, d, total, s); break;
+        case 8: tile_inv<A, 8, false, true>(c, d, total, s); break;
+        case 9: tile_inv<A, 9, false, true>(c, d, total, s); break;
+        case 10: tile_inv<A, 10, false, true>(c, d, total, s); break;
+        case 11: tile_inv<A, 11, false, true>(c, d, total, s); break;
+        default: tile_inv<A, 12, false, true>(c, d, total, s); break;
     }
 }
 
@@ -254,6 +282,17 @@ static size_t ntt_chunk_bytes() {
     return bytes;
 }
 
+static int ntt_top_bits() {
+    static const int bits = [] {
+        if (const char* e = std::getenv("LAMBDA_SNARK_NTT_TOP_BITS")) {
+            const int v = std::atoi(e);
+            if (v >= 1 && v <= 6) return v;
+        }
+        return 4;
+    }();
+    return bits;
+}
+
 static bool ntt_overlap_enabled() {
     static const bool on = [] {
         const char* e = std::getenv("LAMBDA_SNARK_NTT_OVERLAP");
@@ -271,10 +310,12 @@ static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse
         else small_forward<A>(c, d, total, s);
         return;
     }
-    // n > 4096: index bits [12, L) go through strided rounds (at most 4 bits each), bits [0,12) through the tile kernel
-    const int extra = c.logn - kTileLog;
-    const int r_top = std::min(4, extra);
-    const int r_low = extra - r_top;   // 0 or 1
+    // n > 4096: the top `top_bits` index bits go through ONE strided round (up to 6 stages in 64 registers), the low
+    // `lt` bits through the tile kernel.  More strided stages shift VALU work from the ALU-bound tile pass into the
+    // fabric-bound strided pass (LAMBDA_SNARK_NTT_TOP_BITS overrides the default).
+    const int top_bits = std::min(6, std::max(c.logn - kTileLog, std::min(ntt_top_bits(), c.logn - 6)));
+    const int lt = c.logn - top_bits;
+    const int r_top = top_bits;
     // Walk the batch in chunks small enough that the array written by one pass is still resident in the
     // 256 MiB Infinity Cache when the next pass reads it (MI355X_MICROARCH.md "Infinity Cache").
     const size_t chunk_polys = std::max<size_t>(1, ntt_chunk_bytes() >> (c.logn + 3));
@@ -292,11 +333,9 @@ static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse
         hipStream_t cs = overlap ? c.side[chunk_index & 1] : s;
         if (!inverse) {
             strided<A, false, false, true>(c, base, count, c.logn - r_top, r_top, cs);
-            if (r_low) strided<A, false, true, true>(c, base, count, kTileLog, r_low, cs);
-            tile_fwd<A, 12, true, false>(c, base, count, cs);
+            pass_forward<A>(c, lt, base, count, cs);
         } else {
-            tile_inv<A, 12, false, true>(c, base, count, cs);
-            if (r_low) strided<A, true, true, true>(c, base, count, kTileLog, r_low, cs);
+            pass_inverse<A>(c, lt, base, count, cs);
             strided<A, true, true, false>(c, base, count, c.logn - r_top, r_top, cs, add ? add + (first << c.logn) : nullptr);
         }
     }

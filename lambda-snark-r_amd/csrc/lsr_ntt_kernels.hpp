@@ -284,6 +284,14 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
             constexpr bool kNextFinal = (I + 1 == NR - 1) && !RAW_OUT;
             load_round_twiddles<A, LO1, R1, true, kNextFinal>(w[(I + 1) & 1], lane_base<LO1, R1>(t), block_pos, nmask, p.logn, table);
         }
+        uint64_t blind[(kLast && !RAW_OUT) ? kRegs : 1];
+        if constexpr (kLast && !RAW_OUT) {   // request the blinding residues before the last round's arithmetic
+            if (add != nullptr) {
+                const rsrc_t extra = make_rsrc(add + tile_base, tile_bytes);
+#pragma unroll
+                for (int k = 0; k < kRegs; ++k) blind[k] = buf_load64(extra, base * 8u, reg_offset<LO, R>(k) * 8u);
+            }
+        }
         inverse_round<A, LO, R, kFinal>(v, w[I & 1], p, cs);
         if constexpr (!kFinal) {
 #pragma unroll
@@ -291,12 +299,9 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
         }
         if constexpr (kLast) {
             if (!RAW_OUT && add != nullptr) {
-                const rsrc_t extra = make_rsrc(add + tile_base, tile_bytes);
 #pragma unroll
-                for (int k = 0; k < kRegs; ++k) {
-                    const uint64_t e = buf_load64(extra, base * 8u, reg_offset<LO, R>(k) * 8u);
-                    buf_store64(tile, base * 8u, reg_offset<LO, R>(k) * 8u, A::store_reduced_plus(v[k], e, p));
-                }
+                for (int k = 0; k < kRegs; ++k)
+                    buf_store64(tile, base * 8u, reg_offset<LO, R>(k) * 8u, A::store_reduced_plus(v[k], blind[k], p));
             } else {
 #pragma unroll
                 for (int k = 0; k < kRegs; ++k)
@@ -324,10 +329,18 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
     const uint32_t nmask = (1u << p.logn) - 1u;
     const uint32_t pos0 = (uint32_t)(idx0 & nmask);
     elem v[N];
+    constexpr bool kMayAdd = INVERSE && !RAW_OUT;
+    uint64_t extra[kMayAdd ? N : 1];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const uint64_t raw = data[idx0 + ((size_t)k << lo)];
         v[k] = RAW_IN ? elem_from_bits<A>(raw) : A::load(raw, p);
+    }
+    if constexpr (kMayAdd) {   // the blinding residues travel with the operands, not behind the arithmetic
+        if (add != nullptr) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) extra[k] = add[idx0 + ((size_t)k << lo)];
+        }
     }
     if (!INVERSE) {
 #pragma unroll
@@ -376,7 +389,7 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
         const size_t gi = idx0 + ((size_t)k << lo);
         uint64_t out;
         if (RAW_OUT) out = elem_bits<A>(v[k]);
-        else if (INVERSE) out = add != nullptr ? A::store_reduced_plus(v[k], add[gi], p) : A::store_reduced(v[k], p);
+        else if constexpr (kMayAdd) out = add != nullptr ? A::store_reduced_plus(v[k], extra[k], p) : A::store_reduced(v[k], p);
         else out = A::store_canonical(v[k], p);
         data[gi] = out;
     }

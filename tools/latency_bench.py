@@ -1,0 +1,32 @@
+"""Single-call latency of the legacy (host-pointer) C-ABI at the reference's parameters n=4096, k=2."""
+import os, sys, time, ctypes, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry
+pkg = entry.load_package(); lib = pkg._abi.lib()
+def bench(fn, reps=200):
+    for _ in range(10): fn()
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    return (time.perf_counter() - t0) / reps * 1e6
+q, n = 17592169062401, 4096
+ctx = pkg.NttContext(q, n)
+a = (np.arange(n, dtype=np.uint64) * 7919) % q
+print(f"ntt_forward  n=4096 host ptr : {bench(lambda: lib.ntt_forward(ctx.handle, a.ctypes.data, n)):8.1f} us")
+print(f"ntt_inverse  n=4096 host ptr : {bench(lambda: lib.ntt_inverse(ctx.handle, a.ctypes.data, n)):8.1f} us")
+b = a.copy(); r = a.copy()
+print(f"ntt_mul_pointwise n=4096     : {bench(lambda: lib.ntt_mul_pointwise(ctx.handle, r.ctypes.data, a.ctypes.data, b.ctypes.data, n)):8.1f} us")
+t0 = time.perf_counter(); lctx = pkg.LweContext(pkg.Params(q=17592186044417, n=4096, k=2, sigma=3.19)); t1 = time.perf_counter()
+print(f"lwe_context_create           : {(t1-t0)*1e6:8.1f} us")
+msg = np.array([1, 314, 628, 471, 471], dtype=np.uint64)
+held = []
+def commit():
+    p = lib.lwe_commit(lctx.handle, msg.ctypes.data, msg.size, 0x5678); lib.lwe_commitment_free(p)
+print(f"lwe_commit (+free) n=4096 k=2: {bench(commit):8.1f} us   (reference: ~4000-6000 us, ROADMAP.md:344-359)")
+c1 = lib.lwe_commit(lctx.handle, msg.ctypes.data, msg.size, 1); c2 = lib.lwe_commit(lctx.handle, msg.ctypes.data, msg.size, 2)
+print(f"lwe_verify_opening           : {bench(lambda: lib.lwe_verify_opening(lctx.handle, c1, msg.ctypes.data, msg.size, None)):8.1f} us")
+arr = (ctypes.POINTER(pkg._abi.LweCommitment) * 2)(c1, c2); cf = np.array([2, 3], dtype=np.uint64)
+def comb():
+    p = lib.lwe_linear_combine(lctx.handle, arr, cf.ctypes.data, 2); lib.lwe_commitment_free(p)
+print(f"lwe_linear_combine (2 terms) : {bench(comb):8.1f} us")
+buf = np.zeros(4096, dtype=np.uint64)
+print(f"sample_gaussian(4096)        : {bench(lambda: lib.sample_gaussian(buf.ctypes.data, 4096, 3.19), 50):8.1f} us")
