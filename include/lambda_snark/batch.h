@@ -77,11 +77,19 @@ int lwe_commit_batch(LweContext* ctx, const uint64_t* messages, size_t msg_len, 
 
 /* The Module-LWE matrix–vector workload of BASELINE config 3, device-resident:
  *   u_j = INTT( A_hat^T . NTT(r_j) ) + e1_j   for j < batch;   r, e1, u are [batch][k][n] in [0,q).
- * d_e1 == NULL: e1 is sampled on the device from (seeds[j], domain 5, component) — seeds is then a
- * DEVICE-or-host pointer? no: a HOST array of `batch` seeds (copied asynchronously).
- * d_r is overwritten (used as NTT workspace) unless d_r_scratch is given. */
+ * d_e1 != NULL: the blinding residues are read from it (seeds may be NULL).
+ * d_e1 == NULL: e1 is sampled on the device, component i of vector j from the stream (seeds[j], domain 5, i);
+ *               `seeds` is then a HOST array of `batch` seeds and the call returns after the work has finished.
+ * d_r is overwritten with NTT(r).  0 / -1. */
 int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u,
                                  size_t batch, const uint64_t* seeds, void* stream) LSR_NOEXCEPT;
+
+/* ---------------- Fiat–Shamir consumer of the commitment words (host, no GPU needed) ---------------- */
+/* The transcript of rust-api/lambda-snark/src/challenge.rs:102-134: SHA3-256 over "LAMBDA-SNARK-R-FS-v1", the
+ * public inputs and ALL commitment words (each length-prefixed, little-endian); alpha = LE64(h[0..8]) mod modulus.
+ * hash32 may be NULL.  0 / -1. */
+int lsr_fs_challenge(const uint64_t* public_inputs, size_t n_inputs, const LweCommitment* commitment, uint64_t modulus,
+                     uint64_t* alpha, uint8_t* hash32) LSR_NOEXCEPT;
 
 /* ---------------- host-only number theory (usable without a GPU) ---------------- */
 uint64_t lsr_minimal_primitive_root(uint64_t q, uint32_t n) LSR_NOEXCEPT;   /* 0 if none */

@@ -113,3 +113,21 @@ def test_fails_loudly_without_gpu(lib):
 def test_missing_library_fails_loudly(pkg, tmp_path):
     with pytest.raises(ImportError):
         pkg._abi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_fs_challenge_matches_sha3_transcript(lib, pkg):
+    """lsr_fs_challenge is host-only: challenge.rs:102-134 against hashlib's SHA3-256 (FIPS 202)."""
+    import prover_replay
+    rng = np.random.default_rng(7)
+    for n_words, inputs in [(1, []), (5, [1, 471]), (17, [2**64 - 1]), (12293, [1, 91]), (136 // 8 * 3 + 1, list(range(40)))]:
+        words = rng.integers(0, 2**64, size=n_words, dtype=np.uint64)
+        com = pkg._abi.LweCommitment(words.ctypes.data_as(pkg._abi.u64p), n_words)
+        inp = np.array(inputs, dtype=np.uint64)
+        alpha = ctypes.c_uint64(0)
+        digest = (ctypes.c_uint8 * 32)()
+        for q in [17592186044417, 17592169062401, 12289]:
+            assert lib.lsr_fs_challenge(inp.ctypes.data if inputs else None, len(inputs), ctypes.byref(com), q, ctypes.byref(alpha), digest) == 0
+            want_alpha, want_hash = prover_replay.challenge_derive(inputs, words, q)
+            assert alpha.value == want_alpha and bytes(digest) == want_hash
+    assert lib.lsr_fs_challenge(None, 0, None, 12289, ctypes.byref(alpha), None) == -1
+    assert lib.lsr_fs_challenge(None, 0, ctypes.byref(com), 0, ctypes.byref(alpha), None) == -1
