@@ -95,12 +95,35 @@ SIGNATURES = {
 }
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so.7.  Two HIP runtimes in one process fight over the device (the
+    one that initialises second sees no GPU), so when PyTorch is installed its copy is mapped first and
+    liblambda_snark_core.so (NEEDED libamdhip64.so.7) binds to that same runtime.  Without PyTorch the system
+    runtime under /opt/rocm is used, as a Rust or C++ caller would."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        candidate = os.path.join(libdir, name)
+        if os.path.exists(candidate):
+            try:
+                ctypes.CDLL(candidate, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load_library(path=None):
     path = path or LIB_PATH
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
