@@ -211,3 +211,40 @@ def test_config2_full_size_properties(pkg, oracle):
     torch.cuda.synchronize()
     assert torch.equal(a, orig)
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [4096, 65536, 131072])
+def test_f64_flavour_at_its_modulus_bound(pkg, oracle, n):
+    """the FP64-FMA Barrett arithmetic is exact for q < 2^45.  Largest 45-bit primes = 1 (mod 2n),
+    operands that maximise every lazy range (all q-1; alternating; inputs up to 4q-1), forward and inverse."""
+    q = oracle.L.oracle_largest_prime_1mod(2 * n, 45)
+    assert 2**44 < q < 2**45
+    ctx = pkg.NttContext(q, n)
+    assert ctx.uses_f64
+    rows = [np.full(n, q - 1, np.uint64), np.where(np.arange(n) % 2, q - 1, 0).astype(np.uint64), np.where(np.arange(n) % 3, 0, q - 1).astype(np.uint64),
+            oracle.splitmix(11, q, n), oracle.splitmix(12, q, n)]
+    a = np.stack(rows)
+    want = oracle.ntt_forward(q, n, a)
+    assert np.array_equal(ctx.forward_batch(a), want)
+    assert np.array_equal(ctx.forward_batch(a + np.uint64(3 * q)), want)          # lazy inputs < 4q
+    assert np.array_equal(ctx.inverse_batch(a), oracle.ntt_inverse(q, n, a))
+    assert np.array_equal(ctx.inverse_batch(want), a)
+    ctx.close()
+    # one bit above the bound the library must switch to the u64 flavour by itself
+    q46 = oracle.L.oracle_largest_prime_1mod(2 * n, 46)
+    ctx = pkg.NttContext(q46, n)
+    assert not ctx.uses_f64
+    assert np.array_equal(ctx.forward_batch(a % q46), oracle.ntt_forward(q46, n, a % q46))
+    ctx.close()
+
+
+def test_many_random_polynomials_small_prime(pkg, oracle):
+    """q = 12289 (the reference's test prime, test_ntt.cpp:13) across every ring degree it supports, 2048 polynomials."""
+    for n in [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048]:
+        ctx = pkg.NttContext(12289, n)
+        batch = max(3, 8192 // n)
+        a = oracle.splitmix(n, 12289, batch * n).reshape(batch, n)
+        f = ctx.forward_batch(a)
+        assert np.array_equal(f, oracle.ntt_forward(12289, n, a))
+        assert np.array_equal(ctx.inverse_batch(f), a)
+        ctx.close()
