@@ -139,6 +139,25 @@ __global__ void __launch_bounds__(256) add_mod_kernel(uint64_t* __restrict__ dst
     }
 }
 
+// v[j][x] = (v[j][x] + e2[j][x] + delta * (msg[j][x] mod t)) mod q for x < copy, the message term absent beyond:
+// the scalar component's epilogue (e2 blinding + message embedding, commitment.cpp:146-152 truncation/padding)
+__global__ void __launch_bounds__(256) finish_v_kernel(uint64_t* __restrict__ v, const uint64_t* __restrict__ e2, const uint64_t* __restrict__ msgs,
+                                                         uint64_t msg_len, uint64_t copy, uint32_t logn, uint64_t count, uint64_t delta, uint64_t t,
+                                                         uint64_t q) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    const uint64_t nmask = (1ull << logn) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const uint64_t x = i & nmask, j = i >> logn;
+        uint64_t s = v[i] + e2[i];
+        if (s >= q) s -= q;
+        if (x < copy) {
+            s += delta * (msgs[j * msg_len + x] % t);   // delta * (t-1) < q
+            if (s >= q) s -= q;
+        }
+        v[i] = s;
+    }
+}
+
 // acc = (acc + c * x) mod q
 __global__ void __launch_bounds__(256) axpy_mod_kernel(uint64_t* __restrict__ acc, const uint64_t* __restrict__ x, uint64_t c, uint64_t count, ModParams p) {
     const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -270,7 +289,7 @@ static void ensure_workspace(const LweContext& c, size_t batch) {
     c.ws_u.allocate(batch * kn);
     c.ws_e2.allocate(batch * c.n);
     c.ws_v.allocate(batch * c.n);
-    c.ws_dm.allocate(batch * c.n);
+    c.ws_dm.allocate(batch * c.n);   // message slots of a batch (at most n per commitment); verify's message buffer
     c.ws_seeds.allocate(batch);
     if (!c.ws_flag.ptr) c.ws_flag.allocate(1);
     c.ws_batch = batch;
@@ -370,14 +389,18 @@ static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t m
     ensure_workspace(c, batch);
     hipStream_t s = c.ntt->stream;
     // host prep: per-commit seeds (0 => fresh entropy, commitment.h:52) and Delta * (m mod t), truncated / zero-padded to n slots
-    std::vector<uint64_t> seed_host(batch), dm(batch * (size_t)n, 0);
+    std::vector<uint64_t> seed_host(batch);
     const size_t copy = std::min<size_t>(msg_len, n);                       // commitment.cpp:146-149
-    for (size_t j = 0; j < batch; ++j) {
-        seed_host[j] = seeds && seeds[j] ? seeds[j] : (os_entropy64() | 1ull);
-        for (size_t x = 0; x < copy; ++x) dm[j * n + x] = c.delta * (messages[j * msg_len + x] % c.t);
-    }
+    for (size_t j = 0; j < batch; ++j) seed_host[j] = seeds && seeds[j] ? seeds[j] : (os_entropy64() | 1ull);
     LSR_HIP(hipMemcpyAsync(c.ws_seeds.ptr, seed_host.data(), batch * 8, hipMemcpyHostToDevice, s));
-    LSR_HIP(hipMemcpyAsync(c.ws_dm.ptr, dm.data(), dm.size() * 8, hipMemcpyHostToDevice, s));
+    // only the first `copy` slots of each message matter; rows keep their msg_len pitch
+    DeviceBuffer<uint64_t> big_msgs;
+    uint64_t* d_msgs = c.ws_dm.ptr;
+    if (batch * msg_len > c.ws_dm.count) {
+        big_msgs.allocate(batch * msg_len);
+        d_msgs = big_msgs.ptr;
+    }
+    if (copy) LSR_HIP(hipMemcpyAsync(d_msgs, messages, batch * msg_len * 8, hipMemcpyHostToDevice, s));
     launch_gaussian(GaussianJob{c.ws_r.ptr, c.ws_seeds.ptr, 0, k, kDomR, n, batch * k, c.q}, c.cdf.ptr, c.cdf_entries, s);
     launch_gaussian(GaussianJob{c.ws_e1.ptr, c.ws_seeds.ptr, 0, k, kDomE1, n, batch * k, c.q}, c.cdf.ptr, c.cdf_entries, s);
     launch_gaussian(GaussianJob{c.ws_e2.ptr, c.ws_seeds.ptr, 0, 1, kDomE2, n, batch, c.q}, c.cdf.ptr, c.cdf_entries, s);
@@ -386,7 +409,8 @@ static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t m
     matvec(c, c.ws_v.ptr, c.b_hat.ptr, c.ws_r.ptr, nullptr, 1, k, 0, 1, batch, s);
     launch_ntt(*c.ntt, c.ws_v.ptr, batch, true, s);
     const uint64_t vcount = (uint64_t)batch * n;
-    hipLaunchKernelGGL(add_mod_kernel, dim3(grid_for(vcount)), dim3(256), 0, s, c.ws_v.ptr, c.ws_e2.ptr, c.ws_dm.ptr, vcount, c.q);
+    hipLaunchKernelGGL(finish_v_kernel, dim3(grid_for(vcount)), dim3(256), 0, s, c.ws_v.ptr, c.ws_e2.ptr, d_msgs, (uint64_t)msg_len, (uint64_t)copy,
+                       (uint32_t)c.logn, vcount, c.delta, c.t, c.q);
     LSR_HIP(hipGetLastError());
     // gather
     const size_t words = kHeaderWords + kn + n;

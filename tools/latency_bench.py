@@ -30,3 +30,14 @@ def comb():
 print(f"lwe_linear_combine (2 terms) : {bench(comb):8.1f} us")
 buf = np.zeros(4096, dtype=np.uint64)
 print(f"sample_gaussian(4096)        : {bench(lambda: lib.sample_gaussian(buf.ctypes.data, 4096, 3.19), 50):8.1f} us")
+# full commitments (u and v, sampling included, words returned to the host) at the reference's parameters
+batch = 2048
+msgs = (np.arange(batch * 8, dtype=np.uint64).reshape(batch, 8) * 7919) % 1000003
+seeds = np.arange(1, batch + 1, dtype=np.uint64)
+out = (ctypes.POINTER(pkg._abi.LweCommitment) * batch)()
+def cb():
+    assert lib.lwe_commit_batch(lctx.handle, msgs.ctypes.data, 8, batch, seeds.ctypes.data, out) == 0
+    for i in range(batch): lib.lwe_commitment_free(out[i])
+cb()
+t0 = time.perf_counter(); cb(); dt = time.perf_counter() - t0
+print(f"lwe_commit_batch n=4096 k=2 x{batch} (host words out): {dt*1e3:.1f} ms = {batch/dt/1e3:.1f} K commits/s  (reference: ~0.2 K commits/s/core implied, BASELINE.md §2)")
