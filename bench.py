@@ -86,7 +86,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU; the library has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run (any world size)
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     pkg = entry.load_package()
@@ -99,7 +100,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -115,7 +116,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -164,7 +165,7 @@ def main():
             commit_step()
         barrier()
         c_el = time.perf_counter() - c0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([c_el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             c_el = float(t.item())
@@ -193,10 +194,10 @@ def main():
                          "kernel": "forward NTT batch = ntt_strided_round<ArithF64,4> + ntt_tile_forward<ArithF64,12> per 512-poly chunk"},
             "extra": extra,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.cpu_polys)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

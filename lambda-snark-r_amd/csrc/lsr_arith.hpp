@@ -4,10 +4,9 @@
 //    is an exact FP64-FMA Barrett reduction (6 full-rate v_*_f64 instructions, no integer multiplies):
 //        h = x*w            (rounded high part)          l = fma(x, w, -h)   (exact low part)
 //        k = rint(h / q)    (via h * (1/q))              r = fma(-k, q, h) + l
-//    r == x*w (mod q) EXACTLY, with |r| <= ~0.75 q, provided |x * w / q| < 2^49 (DESIGN.md "Exactness
-//    of the f64 path").  Forward CT butterflies need no per-stage correction (|value| grows by < q
-//    per stage, 18 q < 2^50 for q < 2^45); inverse GS butterflies re-centre the sum path once per
-//    radix-16 round.  The final store maps to the canonical representative in [0,q), so the result
+//    r == x*w (mod q) EXACTLY, with |r| <= 0.875 q, provided |x| < 2^50 and q < 2^45 (proof: DESIGN.md §4).
+//    Forward CT butterflies need no per-stage correction (|value| grows by < q per stage, 19 q < 2^50);
+//    inverse GS butterflies re-centre every value once per radix-16 round.  The final store maps to the canonical representative in [0,q), so the result
 //    is bit-identical to the reference's Harvey/Shoup arithmetic (ntt.cpp:84,99 via SEAL).
 //    Measured on MI355X (tools/ubench_arith.hip): 42 cycles per wave-butterfly vs 99 for u64 Shoup.
 //  * ArithU64 (any q < 2^61): SEAL's lazy Harvey butterflies with Shoup multiplication, values in
@@ -24,8 +23,6 @@ struct ModParams {
     uint64_t two_q;    // 2q
     double qd;         // (double) q
     double inv_qd;     // 1.0 / q rounded to nearest
-    uint64_t n_inv;    // n^-1 mod q
-    uint64_t n_inv_shoup;
     uint64_t barrett_hi, barrett_lo;   // floor(2^128 / q) for the pointwise kernel
     int logn;
 };
@@ -88,11 +85,6 @@ __device__ __forceinline__ void buf_store64(rsrc_t r, uint32_t lane_bytes, uint3
 struct ArithF64 {
     using elem = double;     // residue (exact integer in a double)
     using twid = double;     // twiddle (canonical, as double)
-    struct Tables {          // device pointers, stage order (entry m+i)
-        const double* fwd;
-        const double* inv;
-    };
-    static constexpr int kTwiddleWords = 1;
 
     static __device__ __forceinline__ elem load(uint64_t x, const ModParams&) { return f64_from_u52(x); }
     static __device__ __forceinline__ uint64_t store_canonical(elem v, const ModParams& p) {
@@ -144,7 +136,6 @@ struct ArithF64 {
         x = mulmod_f64(a + b, n_inv, p.qd, p.inv_qd);
         y = mulmod_f64(a - b, w_scaled, p.qd, p.inv_qd);
     }
-    static __device__ __forceinline__ void end_of_forward_round(elem&, const ModParams&) {}
     static __device__ __forceinline__ void end_of_inverse_round(elem& v, const ModParams& p) { v = recentre_f64(v, p.qd, p.inv_qd); }
 };
 
@@ -162,11 +153,6 @@ __device__ __forceinline__ uint64_t mul_shoup_lazy(uint64_t x, ShoupOperand o, u
 struct ArithU64 {
     using elem = uint64_t;
     using twid = ShoupOperand;
-    struct Tables {
-        const ShoupOperand* fwd;
-        const ShoupOperand* inv;
-    };
-    static constexpr int kTwiddleWords = 2;
 
     static __device__ __forceinline__ elem load(uint64_t x, const ModParams&) { return x; }
     static __device__ __forceinline__ uint64_t store_canonical(elem v, const ModParams& p) {
@@ -205,7 +191,6 @@ struct ArithU64 {
         x = mul_shoup_lazy(s, n_inv, p.q);
         y = mul_shoup_lazy(u + p.two_q - v, w_scaled, p.q);
     }
-    static __device__ __forceinline__ void end_of_forward_round(elem&, const ModParams&) {}
     static __device__ __forceinline__ void end_of_inverse_round(elem&, const ModParams&) {}
 };
 

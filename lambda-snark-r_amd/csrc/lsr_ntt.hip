@@ -50,14 +50,12 @@ DeviceGuard::~DeviceGuard() {
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
-static ModParams make_mod_params(uint64_t q, int logn, uint64_t n_inv) {
+static ModParams make_mod_params(uint64_t q, int logn) {
     ModParams p{};
     p.q = q;
     p.two_q = 2 * q;
     p.qd = static_cast<double>(q);
     p.inv_qd = 1.0 / static_cast<double>(q);
-    p.n_inv = n_inv;
-    p.n_inv_shoup = shoup_quotient(n_inv, q);
     const u128 ratio = ~static_cast<u128>(0) / q;   // floor((2^128-1)/q) == floor(2^128/q) for odd q > 1
     p.barrett_hi = static_cast<uint64_t>(ratio >> 64);
     p.barrett_lo = static_cast<uint64_t>(ratio);
@@ -96,7 +94,7 @@ NttContext* create_ntt_context(uint64_t q, uint32_t n, int device) {
         ctx->logn = logn;
         ctx->device = device;
         ctx->psi = psi;
-        ctx->mod = make_mod_params(q, logn, tw.n_inv);
+        ctx->mod = make_mod_params(q, logn);
         ctx->use_f64 = (q < (1ull << 45)) && arith_mode() != 1;
         const uint64_t w_last_scaled = mulmod(tw.inv[n > 1 ? 1 : 0], tw.n_inv, q);
         if (ctx->use_f64) {
