@@ -50,9 +50,14 @@ __device__ __forceinline__ double recentre_f64(double v, double q, double inv_q)
     const double k = __builtin_rint(v * inv_q);
     return __builtin_fma(-k, q, v);
 }
+// Canonical representative in [0,q) of an integer |v| <= 32 q, q < 2^45, in three instructions and no select:
+// k = floor(v/q + 2^-46), r = v - k q.  Write v = K q + rho (0 <= rho < q).  The computed v*(1/q) + 2^-46 differs from
+// K + rho/q + 2^-46 by less than 64 * 2^-53 = 2^-47 (two roundings of relative size 2^-53 on a value below 32), so it
+// lies above K (2^-46 > 2^-47) and below K + 1 (1/q > 2^-45 > 2^-46 + 2^-47): the floor is exactly K and the FMA
+// returns rho exactly.
 __device__ __forceinline__ double canonical_f64(double v, double q, double inv_q) {
-    double r = recentre_f64(v, q, inv_q);
-    return r < 0.0 ? r + q : r;
+    const double k = __builtin_floor(__builtin_fma(v, inv_q, 0x1p-46));
+    return __builtin_fma(-k, q, v);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -248,3 +248,22 @@ def test_many_random_polynomials_small_prime(pkg, oracle):
         assert np.array_equal(f, oracle.ntt_forward(12289, n, a))
         assert np.array_equal(ctx.inverse_batch(f), a)
         ctx.close()
+
+
+@pytest.mark.parametrize("q,n", [(Q12, 256), (Q44, 4096), (Q16, 65536), (0, 4096), (0, 131072)])
+def test_outputs_on_the_reduction_boundaries(pkg, oracle, q, n):
+    """The final store maps a lazy value K*q + rho to rho with a biased floor (lsr_arith.hpp canonical_f64); the
+    dangerous residues are rho = 0 and rho = q-1.  Pin forward OUTPUTS to {0, 1, q-2, q-1, random} by feeding the
+    oracle's inverse of that pattern, and likewise inverse outputs.  q = 0 stands for the largest 45-bit prime."""
+    if q == 0:
+        q = oracle.L.oracle_largest_prime_1mod(2 * n, 45)
+    ctx = pkg.NttContext(q, n)
+    rng = np.random.default_rng(9)
+    choices = np.array([0, 1, q - 2, q - 1], dtype=np.uint64)
+    pats = [choices[rng.integers(0, 4, size=n)] for _ in range(3)]
+    pats += [np.where(rng.integers(0, 2, size=n) == 0, choices[rng.integers(0, 4, size=n)], oracle.splitmix(3, q, n)).astype(np.uint64)]
+    pats += [np.zeros(n, np.uint64), np.full(n, q - 1, np.uint64)]
+    want = np.stack(pats)
+    assert np.array_equal(ctx.forward_batch(oracle.ntt_inverse(q, n, want)), want)
+    assert np.array_equal(ctx.inverse_batch(oracle.ntt_forward(q, n, want)), want)
+    ctx.close()
