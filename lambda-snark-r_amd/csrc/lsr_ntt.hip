@@ -198,13 +198,26 @@ static void strided(const NttContext& c, uint64_t* d, size_t total, int lo, int 
     const auto* tw = INVERSE ? Flavour<A>::inv(c) : Flavour<A>::fwd(c);
     const auto cs = Flavour<A>::consts(c);
     const int bpp = affine_bpp_log(c, c.logn - r - 8);   // a polynomial is 2^(logn-r) groups = 2^(logn-r-8) blocks
+    if constexpr (INVERSE && !RAW_OUT) {
+        if (add != nullptr) {
+            switch (r) {
+                case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+                case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+                case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+                case 4: hipLaunchKernelGGL((ntt_strided_round<A, 4, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+                case 5: hipLaunchKernelGGL((ntt_strided_round<A, 5, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+                default: hipLaunchKernelGGL((ntt_strided_round<A, 6, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+            }
+            return;
+        }
+    }
     switch (r) {
-        case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        case 4: hipLaunchKernelGGL((ntt_strided_round<A, 4, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        case 5: hipLaunchKernelGGL((ntt_strided_round<A, 5, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        default: hipLaunchKernelGGL((ntt_strided_round<A, 6, INVERSE, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        case 4: hipLaunchKernelGGL((ntt_strided_round<A, 4, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        case 5: hipLaunchKernelGGL((ntt_strided_round<A, 5, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        default: hipLaunchKernelGGL((ntt_strided_round<A, 6, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
     }
 }
 

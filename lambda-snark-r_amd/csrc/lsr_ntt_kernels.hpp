@@ -315,42 +315,39 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
     });
 }
 
-// ---- strided round kernel (index bits [lo, lo+R), lo >= 12) ----------------------------------------
-template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT>
+// ---- strided round kernel (the TOP R index bits: lo + R == log n) ------------------------------------
+// Its butterfly groups are indexed by the polynomial only, so stage j (register bit j) uses the table entries
+// 2^(R-1-j) + u for every lane of every polynomial: compile-time indices, scalar loads, no VGPRs for twiddles.
+// ADD: canonical residues `add` are added to the outputs in the final store (inverse, last pass only).
+template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT, bool ADD>
 __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
                                                                 const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
                                                                 const uint64_t* __restrict__ add, int bpp_log) {
+    static_assert(!ADD || (INVERSE && !RAW_OUT), "the fused add belongs to the last inverse pass");
     using elem = typename A::elem;
     constexpr int N = 1 << R;
     const size_t group = (size_t)virtual_block(blockIdx.x, bpp_log, gridDim.x) * kThreads + threadIdx.x;
     if (group >= (total >> R)) return;
     const size_t low = group & (((size_t)1 << lo) - 1);
     const size_t idx0 = ((group >> lo) << (lo + R)) | low;
-    const uint32_t nmask = (1u << p.logn) - 1u;
-    const uint32_t pos0 = (uint32_t)(idx0 & nmask);
     elem v[N];
-    constexpr bool kMayAdd = INVERSE && !RAW_OUT;
-    uint64_t extra[kMayAdd ? N : 1];
+    uint64_t extra[ADD ? N : 1];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const uint64_t raw = data[idx0 + ((size_t)k << lo)];
         v[k] = RAW_IN ? elem_from_bits<A>(raw) : A::load(raw, p);
     }
-    if constexpr (kMayAdd) {   // the blinding residues travel with the operands, not behind the arithmetic
-        if (add != nullptr) {
+    if constexpr (ADD) {   // the blinding residues travel with the operands, not behind the arithmetic
 #pragma unroll
-            for (int k = 0; k < N; ++k) extra[k] = add[idx0 + ((size_t)k << lo)];
-        }
+        for (int k = 0; k < N; ++k) extra[k] = add[idx0 + ((size_t)k << lo)];
     }
     if (!INVERSE) {
 #pragma unroll
         for (int j = R - 1; j >= 0; --j) {
-            const int b = lo + j;
             const int half = 1 << j;
-            const uint32_t tw_base = (1u << (p.logn - 1 - b)) + (pos0 >> (b + 1));
 #pragma unroll
             for (int u = 0; u < (1 << (R - 1 - j)); ++u) {
-                const typename A::twid w = A::load_tw(tw, tw_base + u);
+                const typename A::twid w = tw[(1 << (R - 1 - j)) + u];
 #pragma unroll
                 for (int l = 0; l < half; ++l) {
                     const int kx = (u << (j + 1)) | l;
@@ -361,17 +358,15 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
     } else {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            const int b = lo + j;
             const int half = 1 << j;
             if (!RAW_OUT && j == R - 1) {   // the transform's last stage (bit log n - 1)
 #pragma unroll
                 for (int l = 0; l < half; ++l) A::gs_scaled(v[l], v[l + half], cs.w_last_scaled, cs.n_inv, p);
                 continue;
             }
-            const uint32_t tw_base = (1u << (p.logn - 1 - b)) + (pos0 >> (b + 1));
 #pragma unroll
             for (int u = 0; u < (1 << (R - 1 - j)); ++u) {
-                const typename A::twid w = A::load_tw(tw, tw_base + u);
+                const typename A::twid w = tw[(1 << (R - 1 - j)) + u];
 #pragma unroll
                 for (int l = 0; l < half; ++l) {
                     const int kx = (u << (j + 1)) | l;
@@ -389,8 +384,8 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
         const size_t gi = idx0 + ((size_t)k << lo);
         uint64_t out;
         if (RAW_OUT) out = elem_bits<A>(v[k]);
-        else if constexpr (kMayAdd) out = add != nullptr ? A::store_reduced_plus(v[k], extra[k], p) : A::store_reduced(v[k], p);
-        else out = A::store_canonical(v[k], p);
+        else if constexpr (ADD) out = A::store_reduced_plus(v[k], extra[k], p);
+        else out = INVERSE ? A::store_reduced(v[k], p) : A::store_canonical(v[k], p);
         data[gi] = out;
     }
 }
