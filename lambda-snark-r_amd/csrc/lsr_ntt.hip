@@ -120,11 +120,6 @@ NttContext* create_ntt_context(uint64_t q, uint32_t n, int device) {
         }
         ctx->staging.allocate(3ull * n);
         LSR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            LSR_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
-            LSR_HIP(hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming));
-        }
-        LSR_HIP(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
     } catch (const std::exception& e) {
         set_last_error(std::string("ntt_context_create: ") + e.what());
         std::fprintf(stderr, "lambda_snark_core: ntt_context_create failed: %s\n", e.what());
@@ -139,11 +134,6 @@ void destroy_ntt_context(NttContext* ctx) {
     try {
         DeviceGuard guard(ctx->device);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-        for (int i = 0; i < 2; ++i) {
-            if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
-            if (ctx->join_event[i]) (void)hipEventDestroy(ctx->join_event[i]);
-        }
-        if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
         ctx->staging.release();
         ctx->fwd_f64.release();
         ctx->inv_f64.release();
@@ -169,26 +159,16 @@ template <> struct Flavour<ArithU64> {
     static RoundConsts<ArithU64> consts(const NttContext& c) { return {c.n_inv_u64, c.w_last_scaled_u64}; }
 };
 
-// log2(blocks per polynomial) for the XCD-affine block mapping of the two-pass transforms, or -1 (identity)
-static int affine_bpp_log(const NttContext& c, int blocks_log) {
-    static const bool on = [] {
-        const char* e = std::getenv("LAMBDA_SNARK_NTT_XCD_AFFINE");
-        return e && e[0] == '1';
-    }();
-    return (on && c.logn > kTileLog) ? blocks_log : -1;
-}
-
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 static void tile_fwd(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
     const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
-    hipLaunchKernelGGL((ntt_tile_forward<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::fwd(c),
-                       affine_bpp_log(c, c.logn - kTileLog));
+    hipLaunchKernelGGL((ntt_tile_forward<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::fwd(c));
 }
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 static void tile_inv(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* add = nullptr) {
     const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
     hipLaunchKernelGGL((ntt_tile_inverse<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::inv(c),
-                       Flavour<A>::consts(c), add, affine_bpp_log(c, c.logn - kTileLog));
+                       Flavour<A>::consts(c), add);
 }
 
 template <class A, bool INVERSE, bool RAW_IN, bool RAW_OUT>
@@ -197,27 +177,24 @@ static void strided(const NttContext& c, uint64_t* d, size_t total, int lo, int 
     const unsigned grid = static_cast<unsigned>((groups + kThreads - 1) / kThreads);
     const auto* tw = INVERSE ? Flavour<A>::inv(c) : Flavour<A>::fwd(c);
     const auto cs = Flavour<A>::consts(c);
-    const int bpp = affine_bpp_log(c, c.logn - r - 8);   // a polynomial is 2^(logn-r) groups = 2^(logn-r-8) blocks
     if constexpr (INVERSE && !RAW_OUT) {
         if (add != nullptr) {
             switch (r) {
-                case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-                case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-                case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-                case 4: hipLaunchKernelGGL((ntt_strided_round<A, 4, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-                case 5: hipLaunchKernelGGL((ntt_strided_round<A, 5, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-                default: hipLaunchKernelGGL((ntt_strided_round<A, 6, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+                case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add); break;
+                case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add); break;
+                case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add); break;
+                case 4: hipLaunchKernelGGL((ntt_strided_round<A, 4, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add); break;
+                default: hipLaunchKernelGGL((ntt_strided_round<A, 5, true, RAW_IN, false, true>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add); break;
             }
             return;
         }
     }
     switch (r) {
-        case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        case 4: hipLaunchKernelGGL((ntt_strided_round<A, 4, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        case 5: hipLaunchKernelGGL((ntt_strided_round<A, 5, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
-        default: hipLaunchKernelGGL((ntt_strided_round<A, 6, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add, bpp); break;
+        case 1: hipLaunchKernelGGL((ntt_strided_round<A, 1, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add); break;
+        case 2: hipLaunchKernelGGL((ntt_strided_round<A, 2, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add); break;
+        case 3: hipLaunchKernelGGL((ntt_strided_round<A, 3, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add); break;
+        case 4: hipLaunchKernelGGL((ntt_strided_round<A, 4, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add); break;
+        default: hipLaunchKernelGGL((ntt_strided_round<A, 5, INVERSE, RAW_IN, RAW_OUT, false>), dim3(grid), dim3(kThreads), 0, s, d, total, lo, c.mod, tw, cs, add); break;
     }
 }
 
@@ -225,9 +202,6 @@ static void strided(const NttContext& c, uint64_t* d, size_t total, int lo, int 
 template <class A>
 static void pass_forward(const NttContext& c, int lt, uint64_t* d, size_t total, hipStream_t s) {
     switch (lt) {
-        case 6: tile_fwd<A, 6, true, false>(c, d, total, s); break;
-        case 7: tile_fwd<A, 7, true, false>(c, d, total, s); break;
-        case 8: tile_fwd<A, 8, true, false>(c, d, total, s); break;
         case 9: tile_fwd<A, 9, true, false>(c, d, total, s); break;
         case 10: tile_fwd<A, 10, true, false>(c, d, total, s); break;
         case 11: tile_fwd<A, 11, true, false>(c, d, total, s); break;
@@ -237,9 +211,6 @@ static void pass_forward(const NttContext& c, int lt, uint64_t* d, size_t total,
 template <class A>
 static void pass_inverse(const NttContext& c, int lt, uint64_t* d, size_t total, hipStream_t s) {
     switch (lt) {
-        case 6: tile_inv<A, 6, false, true>(c, d, total, s); break;
-        case 7: tile_inv<A, 7, false, true>(c, d, total, s); break;
-        case 8: tile_inv<A, 8, false, true>(c, d, total, s); break;
         case 9: tile_inv<A, 9, false, true>(c, d, total, s); break;
         case 10: tile_inv<A, 10, false, true>(c, d, total, s); break;
         case 11: tile_inv<A, 11, false, true>(c, d, total, s); break;
@@ -293,25 +264,6 @@ static size_t ntt_chunk_bytes() {
     return bytes;
 }
 
-static int ntt_top_bits() {
-    static const int bits = [] {
-        if (const char* e = std::getenv("LAMBDA_SNARK_NTT_TOP_BITS")) {
-            const int v = std::atoi(e);
-            if (v >= 1 && v <= 6) return v;
-        }
-        return 4;
-    }();
-    return bits;
-}
-
-static bool ntt_overlap_enabled() {
-    static const bool on = [] {
-        const char* e = std::getenv("LAMBDA_SNARK_NTT_OVERLAP");
-        return e && e[0] == '1';   // measured: no gain once the fabric is the limiter (profiles/r01_chunk_sweep.txt)
-    }();
-    return on;
-}
-
 template <class A>
 static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s, const uint64_t* add) {
     const size_t total = batch << c.logn;
@@ -321,39 +273,24 @@ static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse
         else small_forward<A>(c, d, total, s);
         return;
     }
-    // n > 4096: the top `top_bits` index bits go through ONE strided round (up to 6 stages in 64 registers), the low
-    // `lt` bits through the tile kernel.  More strided stages shift VALU work from the ALU-bound tile pass into the
-    // fabric-bound strided pass (LAMBDA_SNARK_NTT_TOP_BITS overrides the default).
-    const int top_bits = std::min(6, std::max(c.logn - kTileLog, std::min(ntt_top_bits(), c.logn - 6)));
-    const int lt = c.logn - top_bits;
-    const int r_top = top_bits;
+    // n > 4096: the top 4 (n = 2^17: 5) index bits go through ONE strided round, the low `lt` = 9..12 bits through the
+    // tile kernel.  (5- and 6-stage strided rounds were measured slower at n = 2^16: profiles/README.md.)
+    const int r_top = std::max(c.logn - kTileLog, 4);
+    const int lt = c.logn - r_top;
     // Walk the batch in chunks small enough that the array written by one pass is still resident in the
     // 256 MiB Infinity Cache when the next pass reads it (MI355X_MICROARCH.md "Infinity Cache").
     const size_t chunk_polys = std::max<size_t>(1, ntt_chunk_bytes() >> (c.logn + 3));
-    const bool overlap = ntt_overlap_enabled() && batch > chunk_polys;
-    if (overlap) {
-        LSR_HIP(hipEventRecord(c.fork_event, s));
-        LSR_HIP(hipStreamWaitEvent(c.side[0], c.fork_event, 0));
-        LSR_HIP(hipStreamWaitEvent(c.side[1], c.fork_event, 0));
-    }
-    size_t chunk_index = 0;
-    for (size_t first = 0; first < batch; first += chunk_polys, ++chunk_index) {
+    for (size_t first = 0; first < batch; first += chunk_polys) {
         const size_t now = std::min(chunk_polys, batch - first);
         uint64_t* base = d + (first << c.logn);
         const size_t count = now << c.logn;
-        hipStream_t cs = overlap ? c.side[chunk_index & 1] : s;
+        hipStream_t cs = s;
         if (!inverse) {
             strided<A, false, false, true>(c, base, count, c.logn - r_top, r_top, cs);
             pass_forward<A>(c, lt, base, count, cs);
         } else {
             pass_inverse<A>(c, lt, base, count, cs);
             strided<A, true, true, false>(c, base, count, c.logn - r_top, r_top, cs, add ? add + (first << c.logn) : nullptr);
-        }
-    }
-    if (overlap) {
-        for (int i = 0; i < 2; ++i) {
-            LSR_HIP(hipEventRecord(c.join_event[i], c.side[i]));
-            LSR_HIP(hipStreamWaitEvent(s, c.join_event[i], 0));
         }
     }
 }

@@ -156,20 +156,6 @@ __device__ __forceinline__ void inverse_round(typename A::elem (&v)[kRegs], cons
     }
 }
 
-// XCD-affine virtual block index.  The dispatcher deals workgroups round-robin over the 8 XCDs (block b -> XCD b % 8,
-// observed, speed only).  With `bpp_log` = log2(blocks per polynomial) >= 0 and a grid that is a multiple of
-// 8 << bpp_log, polynomial p's blocks are given hardware indices congruent to p mod 8, so that both passes of a
-// two-pass transform touch p through the same XCD's L2.  bpp_log < 0: identity.
-__device__ __forceinline__ uint32_t virtual_block(uint32_t b, int bpp_log, uint32_t grid) {
-    if (bpp_log < 0) return b;
-    const uint32_t span = 8u << bpp_log;
-    const uint32_t full = grid - (grid % span);
-    if (b >= full) return b;
-    const uint32_t xcd = b & 7u, slot = b >> 3;
-    const uint32_t poly = ((slot >> bpp_log) << 3) | xcd;
-    return (poly << bpp_log) | (slot & ((1u << bpp_log) - 1u));
-}
-
 // ---- tile kernel -----------------------------------------------------------------------------------
 // LT = number of low index bits this kernel transforms (min(L,12)).  RAW_IN / RAW_OUT: the global array
 // holds raw element bit patterns (pass boundary of a two-pass transform) instead of canonical uint64.
@@ -178,13 +164,13 @@ __device__ __forceinline__ uint32_t virtual_block(uint32_t b, int bpp_log, uint3
 // resource's size (loads return 0, stores are dropped).
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restrict__ data, size_t total, ModParams p,
-                                                               const typename A::twid* __restrict__ tw, int bpp_log) {
+                                                               const typename A::twid* __restrict__ tw) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
     using twid = typename A::twid;
     constexpr int NR = TileRound<LT, 0>::kCount;
     const uint32_t t = threadIdx.x;
-    const size_t tile_base = (size_t)virtual_block(blockIdx.x, bpp_log, gridDim.x) * kTile;
+    const size_t tile_base = (size_t)blockIdx.x * kTile;
     const uint32_t nmask = (1u << p.logn) - 1u;
     const uint32_t block_pos = (uint32_t)(tile_base & nmask);
     const size_t left = total - tile_base;
@@ -239,13 +225,13 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restric
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restrict__ data, size_t total, ModParams p,
                                                                const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
-                                                               const uint64_t* __restrict__ add, int bpp_log) {
+                                                               const uint64_t* __restrict__ add) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
     using twid = typename A::twid;
     constexpr int NR = TileRound<LT, 0>::kCount;
     const uint32_t t = threadIdx.x;
-    const size_t tile_base = (size_t)virtual_block(blockIdx.x, bpp_log, gridDim.x) * kTile;
+    const size_t tile_base = (size_t)blockIdx.x * kTile;
     const uint32_t nmask = (1u << p.logn) - 1u;
     const uint32_t block_pos = (uint32_t)(tile_base & nmask);
     const size_t left = total - tile_base;
@@ -322,11 +308,11 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
 template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT, bool ADD>
 __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
                                                                 const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
-                                                                const uint64_t* __restrict__ add, int bpp_log) {
+                                                                const uint64_t* __restrict__ add) {
     static_assert(!ADD || (INVERSE && !RAW_OUT), "the fused add belongs to the last inverse pass");
     using elem = typename A::elem;
     constexpr int N = 1 << R;
-    const size_t group = (size_t)virtual_block(blockIdx.x, bpp_log, gridDim.x) * kThreads + threadIdx.x;
+    const size_t group = (size_t)blockIdx.x * kThreads + threadIdx.x;
     if (group >= (total >> R)) return;
     const size_t low = group & (((size_t)1 << lo) - 1);
     const size_t idx0 = ((group >> lo) << (lo + R)) | low;

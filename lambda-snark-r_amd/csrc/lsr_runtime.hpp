@@ -91,11 +91,6 @@ struct NttContext {
     mutable std::mutex staging_mutex;
     mutable lsr::DeviceBuffer<uint64_t> staging;   // 3 n words
     hipStream_t stream = nullptr;
-    // fork/join helpers for the two-pass transforms: consecutive chunks alternate between two side
-    // streams so that the memory-bound strided pass of one chunk overlaps the ALU-bound tile pass of the other
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t fork_event = nullptr;
-    hipEvent_t join_event[2] = {nullptr, nullptr};
 };
 
 namespace lsr {
