@@ -1,0 +1,30 @@
+"""CPU sanitizers (the reference offers LAMBDA_SNARK_USE_ASAN/UBSAN but never enables them): the oracle and
+the library's host-only code run under AddressSanitizer + UndefinedBehaviorSanitizer through native drivers.  GPU-side
+sanitizers are not available on this pool."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+
+
+def run(cmd, **kw):
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, **kw)
+    assert out.returncode == 0, out.stdout[-4000:]
+    return out.stdout
+
+
+def test_oracle_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "oracle_san")
+    run(["gcc", "-std=c11", *SAN, "-I" + os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests/c/oracle_sanitizer_driver.c"),
+         os.path.join(ROOT, "oracle/lsr_oracle.c"), "-lm", "-o", exe])
+    assert "ok" in run([exe], env=ENV)
+
+
+def test_library_host_code_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "host_san")
+    csrc = os.path.join(ROOT, "lambda-snark-r_amd/csrc")
+    run(["g++", "-std=c++17", *SAN, "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(ROOT, "tests/c/host_sanitizer_driver.cpp"),
+         os.path.join(csrc, "lsr_host_math.cpp"), os.path.join(csrc, "lsr_transcript.cpp"), "-o", exe])
+    assert "ok" in run([exe], env=ENV)
