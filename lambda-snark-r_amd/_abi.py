@@ -40,6 +40,21 @@ class LweOpening(ctypes.Structure):
     _fields_ = [("randomness", u64p), ("rand_len", ctypes.c_size_t)]
 
 
+class SparseEntry(ctypes.Structure):
+    """reference cpp-core/include/lambda_snark/r1cs.h:38-42"""
+    _fields_ = [("row", ctypes.c_uint32), ("col", ctypes.c_uint32), ("value", ctypes.c_uint64)]
+
+
+class SparseMatrix(ctypes.Structure):
+    """reference r1cs.h:49-54"""
+    _fields_ = [("entries", ctypes.POINTER(SparseEntry)), ("n_entries", ctypes.c_size_t), ("n_rows", ctypes.c_uint32), ("n_cols", ctypes.c_uint32)]
+
+
+class R1CSWitness(ctypes.Structure):
+    """reference r1cs.h:76-79"""
+    _fields_ = [("values", u64p), ("len", ctypes.c_size_t)]
+
+
 PROFILE_SCALAR_A = 0
 PROFILE_RING_B = 1
 
@@ -90,6 +105,12 @@ SIGNATURES = {
     "lsr_mlwe_matvec_batch_device": (c_int, [vp, vp, vp, vp, c_size, vp, vp]),
     "lsr_fs_challenge": (c_int, [vp, c_size, ctypes.POINTER(LweCommitment), u64, vp, vp]),
     "lsr_minimal_primitive_root": (u64, [u64, u32]),
+    # r1cs.h (SEAL/NTL-free shim, host only)
+    "lambda_snark_r1cs_create": (c_int, [ctypes.POINTER(SparseMatrix), ctypes.POINTER(SparseMatrix), ctypes.POINTER(SparseMatrix), u64, ctypes.POINTER(vp)]),
+    "lambda_snark_r1cs_validate_witness": (c_int, [vp, ctypes.POINTER(R1CSWitness), ctypes.POINTER(ctypes.c_bool)]),
+    "lambda_snark_r1cs_free": (None, [vp]),
+    "lambda_snark_r1cs_num_constraints": (u32, [vp]),
+    "lambda_snark_r1cs_num_variables": (u32, [vp]),
     "lsr_select_commit_modulus": (u64, [u64, u32]),
     "lsr_plain_modulus": (u64, [u32]),
 }

@@ -21,7 +21,7 @@ def declared_symbols():
         text = re.sub(r"//[^\n]*", "", text)
         for m in re.finditer(r"\b([a-z_][a-z0-9_]*)\s*\(", text):
             name = m.group(1)
-            if name.startswith(("ntt_", "lwe_", "lsr_", "sample_gaussian")):
+            if name.startswith(("ntt_", "lwe_", "lsr_", "sample_gaussian", "lambda_snark_r1cs_")):
                 names.add(name)
     return names
 
