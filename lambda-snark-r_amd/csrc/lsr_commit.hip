@@ -15,6 +15,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <thread>
 #include <type_traits>
 
 #include "lambda_snark/batch.h"
@@ -233,6 +234,9 @@ struct LweContext {
     mutable lsr::DeviceBuffer<uint64_t> ws_r, ws_e1, ws_e2, ws_u, ws_v, ws_dm, ws_seeds;
     mutable lsr::DeviceBuffer<unsigned long long> ws_flag;
     mutable size_t ws_batch = 0;
+    // pinned host staging for the gather of a batch (two bulk D2H copies instead of two per commitment)
+    mutable uint64_t* host_stage = nullptr;
+    mutable size_t host_stage_words = 0;
 };
 
 namespace lsr {
@@ -360,6 +364,7 @@ static void destroy_lwe_context(LweContext* c) {
         c->a_hat.release(); c->s_hat.release(); c->b_hat.release(); c->cdf.release();
         c->ws_r.release(); c->ws_e1.release(); c->ws_e2.release(); c->ws_u.release(); c->ws_v.release();
         c->ws_dm.release(); c->ws_seeds.release(); c->ws_flag.release();
+        if (c->host_stage) (void)hipHostFree(c->host_stage);
     } catch (...) {
     }
     destroy_ntt_context(c->ntt);
@@ -412,21 +417,24 @@ static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t m
     hipLaunchKernelGGL(finish_v_kernel, dim3(grid_for(vcount)), dim3(256), 0, s, c.ws_v.ptr, c.ws_e2.ptr, d_msgs, (uint64_t)msg_len, (uint64_t)copy,
                        (uint32_t)c.logn, vcount, c.delta, c.t, c.q);
     LSR_HIP(hipGetLastError());
-    // gather
+    // gather: u and v of the whole chunk come back in two bulk copies into pinned memory; the per-commitment arrays
+    // (which the ABI wants as separate new[] allocations, commitment.cpp:50-57) are filled from there by a few threads
     const size_t words = kHeaderWords + kn + n;
+    const size_t stage_words = batch * (kn + n);
+    if (stage_words > c.host_stage_words) {
+        if (c.host_stage) (void)hipHostFree(c.host_stage);
+        c.host_stage = nullptr;
+        c.host_stage_words = 0;
+        LSR_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host_stage), stage_words * 8, hipHostMallocDefault));
+        c.host_stage_words = stage_words;
+    }
+    uint64_t* const stage_u = c.host_stage;
+    uint64_t* const stage_v = c.host_stage + batch * kn;
+    LSR_HIP(hipMemcpyAsync(stage_u, c.ws_u.ptr, batch * kn * 8, hipMemcpyDeviceToHost, s));
+    LSR_HIP(hipMemcpyAsync(stage_v, c.ws_v.ptr, batch * (size_t)n * 8, hipMemcpyDeviceToHost, s));
     std::vector<LweCommitment*> made(batch, nullptr);
     try {
-        for (size_t j = 0; j < batch; ++j) {
-            made[j] = new_commitment(words);
-            uint64_t* d = made[j]->data;
-            d[0] = 8ull * (words - 1);
-            d[1] = kWireMagic;
-            d[2] = (uint64_t)n | ((uint64_t)k << 32);
-            d[3] = c.q;
-            d[4] = c.t;
-            LSR_HIP(hipMemcpyAsync(d + kHeaderWords, c.ws_u.ptr + j * kn, kn * 8, hipMemcpyDeviceToHost, s));
-            LSR_HIP(hipMemcpyAsync(d + kHeaderWords + kn, c.ws_v.ptr + j * n, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-        }
+        for (size_t j = 0; j < batch; ++j) made[j] = new_commitment(words);   // overlaps the copies
         LSR_HIP(hipStreamSynchronize(s));
     } catch (...) {
         (void)hipStreamSynchronize(s);
@@ -434,6 +442,30 @@ static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t m
             if (m) { delete[] m->data; delete m; }
         }
         throw;
+    }
+    auto fill = [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+            uint64_t* d = made[j]->data;
+            d[0] = 8ull * (words - 1);
+            d[1] = kWireMagic;
+            d[2] = (uint64_t)n | ((uint64_t)k << 32);
+            d[3] = c.q;
+            d[4] = c.t;
+            std::memcpy(d + kHeaderWords, stage_u + j * kn, kn * 8);
+            std::memcpy(d + kHeaderWords + kn, stage_v + j * n, (size_t)n * 8);
+        }
+    };
+    const size_t workers = std::min<size_t>(8, std::max<size_t>(1, (batch * words * 8) >> 22));   // one thread per ~4 MiB, at most 8
+    if (workers <= 1) {
+        fill(0, batch);
+    } else {
+        std::vector<std::thread> pool;
+        const size_t per = (batch + workers - 1) / workers;
+        for (size_t w = 0; w < workers; ++w) {
+            const size_t lo = w * per, hi = std::min(batch, lo + per);
+            if (lo < hi) pool.emplace_back(fill, lo, hi);
+        }
+        for (std::thread& th : pool) th.join();
     }
     for (size_t j = 0; j < batch; ++j) out[j] = made[j];
 }
