@@ -75,6 +75,12 @@ int lsr_lwe_public_matrix(const LweContext* ctx, uint64_t* a_hat) LSR_NOEXCEPT;
 int lwe_commit_batch(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch,
                      const uint64_t* seeds, LweCommitment** out) LSR_NOEXCEPT;
 
+/* `count` openings in one device pass.  messages = [count][msg_len]; results[i] = 1 / 0 / -1 with the meaning of
+ * lwe_verify_opening (cpp-core/src/commitment.cpp:200-232) for (commitments[i], messages[i]); NULL entries => -1.
+ * Returns 0, or -1 if the call itself failed. */
+int lwe_verify_opening_batch(const LweContext* ctx, const LweCommitment* const* commitments, const uint64_t* messages,
+                             size_t msg_len, size_t count, int* results) LSR_NOEXCEPT;
+
 /* The Module-LWE matrix–vector workload of BASELINE config 3, device-resident:
  *   u_j = INTT( A_hat^T . NTT(r_j) ) + e1_j   for j < batch;   r, e1, u are [batch][k][n] in [0,q).
  * d_e1 != NULL: the blinding residues are read from it (seeds may be NULL).

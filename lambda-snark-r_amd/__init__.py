@@ -20,7 +20,7 @@ from ._abi import PROFILE_RING_B, PROFILE_SCALAR_A, LweCommitment, LweOpening, P
 
 __all__ = [
     "NttContext", "LweContext", "Commitment", "Params", "CoreError", "verify_opening_with_context",
-    "sample_gaussian", "PublicParams", "PROFILE_RING_B", "PROFILE_SCALAR_A",
+    "sample_gaussian", "verify_openings_batch", "PublicParams", "PROFILE_RING_B", "PROFILE_SCALAR_A",
 ]
 
 
@@ -258,6 +258,18 @@ def verify_opening_with_context(ctx, commitment, message, randomness=None):
     if rc < 0:
         raise CoreError("lwe_verify_opening returned -1")
     return rc == 1
+
+
+def verify_openings_batch(ctx, commitments, messages):
+    """``lwe_verify_opening_batch``: messages [count][msg_len] (reduced mod ctx.modulus() like opening.rs:198-201);
+    returns a list of 1 / 0 / -1."""
+    lib = _abi.lib()
+    msgs = np.ascontiguousarray([[int(m) % ctx.modulus() for m in row] for row in messages], dtype=np.uint64)
+    arr = (ctypes.POINTER(LweCommitment) * len(commitments))(*[c._p if c is not None else None for c in commitments])
+    out = np.zeros(len(commitments), dtype=np.int32)
+    if lib.lwe_verify_opening_batch(ctx.handle, arr, msgs.ctypes.data, msgs.shape[1] if msgs.ndim == 2 else 0, len(commitments), out.ctypes.data) != 0:
+        raise CoreError("lwe_verify_opening_batch failed: " + _abi.last_error())
+    return [int(x) for x in out]
 
 
 def sample_gaussian(length, sigma, seed=None, domain=16, index=0):

@@ -209,6 +209,21 @@ __global__ void __launch_bounds__(256) decode_compare_kernel(const uint64_t* __r
     if (diff) atomicOr(flag, (unsigned long long)diff);
 }
 
+// batched form: flags[j] |= OR_i decode(w[j][i]) xor (msg[j][i] mod t), one lane per (j, i)
+__global__ void __launch_bounds__(256) decode_compare_batch_kernel(const uint64_t* __restrict__ w, const uint64_t* __restrict__ msgs, uint64_t msg_len,
+                                                                     uint32_t logn, uint64_t count, uint64_t t, ModParams p,
+                                                                     unsigned long long* __restrict__ flags) {
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= count * msg_len) return;
+    const uint64_t j = gid / msg_len, i = gid - j * msg_len;
+    const uint64_t wi = w[(j << logn) + i];
+    const uint64_t lo0 = wi * t, hi0 = __umul64hi(wi, t);
+    const uint64_t lo = lo0 + (p.q >> 1);
+    const uint64_t hi = hi0 + (lo < lo0);
+    const uint64_t diff = (div128_by_q(hi, lo, p) % t) ^ (msgs[gid] % t);
+    if (diff) atomicOr(&flags[j], (unsigned long long)diff);
+}
+
 static unsigned grid_for(uint64_t work, unsigned cap = 256 * 16) {
     const uint64_t blocks = (work + 255) / 256;
     return static_cast<unsigned>(std::min<uint64_t>(blocks, cap));
@@ -515,6 +530,59 @@ static int verify_opening(const LweContext& c, const LweCommitment* cm, const ui
     return flag == 0 ? 1 : 0;
 }
 
+// Many openings in one device pass.  results[i]: 1 / 0 / -1 exactly as the single call.
+static void verify_opening_batch(const LweContext& c, const LweCommitment* const* cms, const uint64_t* messages, size_t msg_len, size_t count,
+                                 int* results) {
+    const uint32_t n = c.n, k = c.k;
+    const size_t kn = (size_t)k * n;
+    std::vector<size_t> live;           // indices that reach the device
+    std::vector<const uint64_t*> bodies;
+    for (size_t i = 0; i < count; ++i) {
+        const uint64_t* body = nullptr;
+        if (!cms[i] || !parse_commitment(c, cms[i], &body)) { results[i] = -1; continue; }
+        bool canonical = true;
+        for (size_t x = 0; x < kn + n && canonical; ++x) canonical = body[x] < c.q;
+        if (!canonical) { results[i] = -1; continue; }
+        if (msg_len > n) { results[i] = 0; continue; }
+        if (msg_len == 0) { results[i] = 1; continue; }
+        live.push_back(i);
+        bodies.push_back(body);
+    }
+    if (live.empty()) return;
+    DeviceGuard guard(c.device);
+    std::lock_guard<std::mutex> lock(c.mutex);
+    hipStream_t s = c.ntt->stream;
+    const size_t per_opening = (3 * (size_t)k + 3) * n * 8;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(live.size(), (1ull << 30) / per_opening));
+    ensure_workspace(c, chunk);
+    DeviceBuffer<unsigned long long> flags(chunk);
+    DeviceBuffer<uint64_t> d_msgs(chunk * msg_len);
+    std::vector<unsigned long long> host_flags(chunk);
+    std::vector<uint64_t> host_msgs(chunk * msg_len);
+    for (size_t first = 0; first < live.size(); first += chunk) {
+        const size_t now = std::min(chunk, live.size() - first);
+        for (size_t j = 0; j < now; ++j) {
+            LSR_HIP(hipMemcpyAsync(c.ws_u.ptr + j * kn, bodies[first + j], kn * 8, hipMemcpyHostToDevice, s));
+            LSR_HIP(hipMemcpyAsync(c.ws_v.ptr + j * n, bodies[first + j] + kn, (size_t)n * 8, hipMemcpyHostToDevice, s));
+            std::memcpy(host_msgs.data() + j * msg_len, messages + live[first + j] * msg_len, msg_len * 8);
+        }
+        LSR_HIP(hipMemcpyAsync(d_msgs.ptr, host_msgs.data(), now * msg_len * 8, hipMemcpyHostToDevice, s));
+        LSR_HIP(hipMemsetAsync(flags.ptr, 0, now * sizeof(unsigned long long), s));
+        launch_ntt(*c.ntt, c.ws_u.ptr, now * k, false, s);
+        launch_ntt(*c.ntt, c.ws_v.ptr, now, false, s);
+        matvec(c, c.ws_e2.ptr, c.s_hat.ptr, c.ws_u.ptr, nullptr, 1, k, 0, 1, now, s);            // <s_hat, u_hat>
+        hipLaunchKernelGGL(rsub_mod_kernel, dim3(grid_for(now * n)), dim3(256), 0, s, c.ws_e2.ptr, c.ws_v.ptr, (uint64_t)now * n, c.q);
+        launch_ntt(*c.ntt, c.ws_e2.ptr, now, true, s);
+        const uint64_t lanes = (uint64_t)now * msg_len;
+        hipLaunchKernelGGL(decode_compare_batch_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, c.ws_e2.ptr, d_msgs.ptr, (uint64_t)msg_len,
+                           (uint32_t)c.logn, (uint64_t)now, c.t, c.ntt->mod, flags.ptr);
+        LSR_HIP(hipGetLastError());
+        LSR_HIP(hipMemcpyAsync(host_flags.data(), flags.ptr, now * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipStreamSynchronize(s));
+        for (size_t j = 0; j < now; ++j) results[live[first + j]] = host_flags[j] == 0 ? 1 : 0;
+    }
+}
+
 static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** cms, const uint64_t* coeffs, size_t count) {
     const size_t body_words = (size_t)(c.k + 1) * c.n;
     DeviceGuard guard(c.device);
@@ -673,6 +741,22 @@ int lwe_verify_opening(const LweContext* ctx, const LweCommitment* commitment, c
         return lsr::verify_opening(*ctx, commitment, message, msg_len);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "lwe_verify_opening error: %s\n", e.what());         // commitment.cpp:229-231
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
+int lwe_verify_opening_batch(const LweContext* ctx, const LweCommitment* const* commitments, const uint64_t* messages, size_t msg_len, size_t count,
+                             int* results) noexcept {
+    if (!ctx || !commitments || !messages || !results) return -1;
+    if (count == 0) return 0;
+    try {
+        lsr::verify_opening_batch(*ctx, commitments, messages, msg_len, count, results);
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lwe_verify_opening_batch: ") + e.what());
+        std::fprintf(stderr, "lwe_verify_opening error: %s\n", e.what());
         return -1;
     } catch (...) {
         return -1;

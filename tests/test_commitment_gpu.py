@@ -280,3 +280,29 @@ def test_config3_matvec_workload(pkg, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(d_u.cpu().numpy().view(np.uint64), want)
     lctx.close()
+
+
+def test_verify_opening_batch_matches_single_calls(pkg, oracle):
+    """lwe_verify_opening_batch: same 1 / 0 / -1 as one lwe_verify_opening per entry, and as the oracle."""
+    q, n, k = 17592186044417, 4096, 2
+    lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=KEY)
+    count, msg_len = 37, 5
+    rng = np.random.default_rng(3)
+    msgs = rng.integers(0, 1000, size=(count, msg_len)).astype(np.uint64)
+    coms = pkg.Commitment.batch(lctx, msgs, np.arange(1, count + 1, dtype=np.uint64))
+    claimed = msgs.copy()
+    wrong = [3, 11, 36]
+    for w in wrong:
+        claimed[w, w % msg_len] += 1
+    entries = list(coms)
+    entries[5] = None                                      # NULL entry => -1
+    got = pkg.verify_openings_batch(lctx, entries, claimed)
+    want = [(-1 if i == 5 else (0 if i in wrong else 1)) for i in range(count)]
+    assert got == want
+    for i in (0, 3, 11, 20):
+        assert int(pkg.verify_opening_with_context(lctx, coms[i], claimed[i])) == want[i]
+        assert oracle.lwe_verify(q, n, k, 3.19, KEY, coms[i].as_words(), [int(x) for x in claimed[i]]) == want[i]
+    # linear combinations verify in the same pass
+    comb = pkg.Commitment.linear_combine(lctx, [coms[0], coms[1]], [2, 3])
+    assert pkg.verify_openings_batch(lctx, [comb, comb], [2 * msgs[0] + 3 * msgs[1], 2 * msgs[0] + 3 * msgs[1] + 1]) == [1, 0]
+    lctx.close()
