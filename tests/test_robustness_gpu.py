@@ -104,3 +104,31 @@ def test_randomized_small_cases(pkg, oracle):
         b = rng.integers(0, q, size=n, dtype=np.uint64)
         assert np.array_equal(ctx.mul_pointwise(a[0], b), oracle.mul_pointwise(q, n, a[0], b))
         ctx.close()
+
+
+def test_device_api_is_graph_capturable(pkg, oracle):
+    """The device-resident entry points only enqueue kernels (no allocation, no synchronisation), so a caller can
+    capture them into a HIP graph and replay it (launch-bound loops, e.g. many small batches)."""
+    import torch
+    q, n, batch = 17592182243329, 65536, 4
+    ctx = pkg.NttContext(q, n, device=0)
+    host = oracle.splitmix(21, q, batch * n).reshape(batch, n)
+    buf = torch.from_numpy(host.view(np.int64)).cuda()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):      # warm-up outside capture
+        ctx.forward_device(buf.data_ptr(), batch, side.cuda_stream)
+        ctx.inverse_device(buf.data_ptr(), batch, side.cuda_stream)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        ctx.forward_device(buf.data_ptr(), batch, torch.cuda.current_stream().cuda_stream)
+    buf.copy_(torch.from_numpy(host.view(np.int64)))
+    graph.replay()
+    torch.cuda.synchronize()
+    want = oracle.ntt_forward(q, n, host)
+    assert np.array_equal(buf.cpu().numpy().view(np.uint64), want)
+    graph.replay()                     # second replay transforms the transformed data: compare with the oracle again
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy().view(np.uint64), oracle.ntt_forward(q, n, want))
+    ctx.close()
