@@ -200,7 +200,8 @@ def main():
             "metric": "degree-2^16 NTTs/sec (forward+inverse, batched, device-resident)",
             "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 residues (exact f64-FMA Barrett arithmetic)" if ctx.uses_f64 else "u64", "data": "synthetic",
+            "dtype": "f64" if ctx.uses_f64 else "u64",      # exact integer residues held in FP64 registers (FMA Barrett); I/O is uint64
+            "data": "synthetic",
             "config": {"workload": "config2: batched forward+inverse negacyclic NTT, n=2^16, 4096 polys/GPU, q=17592182243329 (44-bit)",
                        "polys_per_gpu": args.polys, "ring_degree": N, "modulus": Q16, "parallelism": f"independent batches x{world}, no collectives"},
             # achieved = ALGORITHMIC bytes (1 MiB per transform) / measured time of one forward batch launch sequence

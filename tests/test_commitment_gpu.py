@@ -165,7 +165,8 @@ def test_seeded_sampler_bit_exact(pkg, oracle, sigma, length):
 
 # ---- bit-exactness against the oracle -------------------------------------------------------------------
 @pytest.mark.parametrize("q,n,k", [(12289, 4096, 2), (17592186044417, 4096, 2), (12289, 256, 2), (17592186044417, 1024, 4),
-                                   (1152921504606584833, 4096, 1), (12289, 8192, 3)])
+                                   (1152921504606584833, 4096, 1), (12289, 8192, 3), (12289, 512, 5), (1152921504606584833, 256, 7),
+                                   (12289, 2, 1), (12289, 64, 16)])
 def test_commit_bit_exact_vs_oracle(pkg, oracle, q, n, k):
     lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=KEY)
     oq, a_hat = oracle.lwe_public_matrix(q, n, k, 3.19, KEY)
