@@ -9,6 +9,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 tools/ntt_bench.py > $out/pmc_$c.log 2>&1
+  J=256 timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $out/pmc_commit_$c -- python3 tools/commit_bench.py > $out/pmc_commit_$c.log 2>&1
 done
 python3 - $out <<'PY'
 import csv, glob, sys, collections, json
@@ -24,4 +25,15 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k in acc: res[k][c + "_KiB_per_dispatch"] = acc[k] / cnt[k]; res[k]["dispatches"] = cnt[k]
 json.dump(res, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
+# commit workload (J = 256 witness vectors per dispatch sequence): bytes per kernel, FETCH_SIZE already doubled
+com = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"{out}/pmc_commit_{c}/*/*counter_collection.csv")[0]
+    acc = collections.defaultdict(float); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void lsr::", "")
+        if "lsr" not in r["Kernel_Name"] or r["Counter_Name"] != c: continue
+        acc[k] += float(r["Counter_Value"]); cnt[k] += 1
+    for k in acc: com[k][c + "_KiB_total"] = acc[k]; com[k]["dispatches"] = cnt[k]
+json.dump(com, open(f"{out}/pmc_commit_traffic.json", "w"), indent=1)
 PY
