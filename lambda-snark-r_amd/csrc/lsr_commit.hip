@@ -374,7 +374,9 @@ static void destroy_lwe_context(LweContext* c) {
     if (!c) return;
     try {
         DeviceGuard guard(c->device);
-        if (c->s_hat.ptr) (void)hipMemset(c->s_hat.ptr, 0, c->s_hat.count * 8);   // zeroize the secret (commitment.h:34)
+        // zeroize the secret key and the scratch that held commitment randomness (commitment.h:34)
+        for (lsr::DeviceBuffer<uint64_t>* b : {&c->s_hat, &c->ws_r, &c->ws_e1, &c->ws_e2})
+            if (b->ptr) (void)hipMemset(b->ptr, 0, b->count * 8);
         (void)hipDeviceSynchronize();
         c->a_hat.release(); c->s_hat.release(); c->b_hat.release(); c->cdf.release();
         c->ws_r.release(); c->ws_e1.release(); c->ws_e2.release(); c->ws_u.release(); c->ws_v.release();
