@@ -132,8 +132,9 @@ class Oracle:
         assert h
         words = self.L.oracle_lwe_commit_words(h)
         out = np.zeros(words, dtype=np.uint64)
-        m = np.array([int(x) for x in msg], dtype=np.uint64)
-        assert self.L.oracle_lwe_commit(h, m.ctypes.data, m.size, seed, out.ctypes.data) == 0
+        vals = [int(x) for x in msg]
+        m = np.array(vals or [0], dtype=np.uint64)          # never hand the oracle a NULL pointer for an empty message
+        assert self.L.oracle_lwe_commit(h, m.ctypes.data, len(vals), seed, out.ctypes.data) == 0
         return out
 
     def lwe_verify(self, q, n, k, sigma, key_seed, comm_words, msg):

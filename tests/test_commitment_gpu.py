@@ -166,7 +166,7 @@ def test_seeded_sampler_bit_exact(pkg, oracle, sigma, length):
 # ---- bit-exactness against the oracle -------------------------------------------------------------------
 @pytest.mark.parametrize("q,n,k", [(12289, 4096, 2), (17592186044417, 4096, 2), (12289, 256, 2), (17592186044417, 1024, 4),
                                    (1152921504606584833, 4096, 1), (12289, 8192, 3), (12289, 512, 5), (1152921504606584833, 256, 7),
-                                   (12289, 2, 1), (12289, 64, 16)])
+                                   (12289, 2, 1), (12289, 64, 16), (12289, 131072, 1)])
 def test_commit_bit_exact_vs_oracle(pkg, oracle, q, n, k):
     lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=KEY)
     oq, a_hat = oracle.lwe_public_matrix(q, n, k, 3.19, KEY)
@@ -306,4 +306,22 @@ def test_verify_opening_batch_matches_single_calls(pkg, oracle):
     # linear combinations verify in the same pass
     comb = pkg.Commitment.linear_combine(lctx, [coms[0], coms[1]], [2, 3])
     assert pkg.verify_openings_batch(lctx, [comb, comb], [2 * msgs[0] + 3 * msgs[1], 2 * msgs[0] + 3 * msgs[1] + 1]) == [1, 0]
+    lctx.close()
+
+
+def test_empty_message_and_zero_length_openings(pkg, lib, oracle):
+    """msg_len = 0 is legal at the ABI (commitment.cpp:146-149 copies min(msg_len, slots) = 0 values): a commitment to the
+    all-zero message; an opening of zero slots is vacuously valid."""
+    q, n, k = 17592186044417, 4096, 2
+    lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=KEY)
+    one = np.array([5], dtype=np.uint64)
+    p = lib.lwe_commit(lctx.handle, one.ctypes.data, 0, 77)
+    assert p
+    assert np.array_equal(words(p), oracle.lwe_commit(q, n, k, 3.19, KEY, [], 77))
+    assert np.array_equal(words(p), oracle.lwe_commit(q, n, k, 3.19, KEY, [0, 0, 0], 77))
+    assert lib.lwe_verify_opening(lctx.handle, p, one.ctypes.data, 0, None) == 1
+    zeros = np.zeros(n, dtype=np.uint64)
+    assert lib.lwe_verify_opening(lctx.handle, p, zeros.ctypes.data, n, None) == 1
+    assert lib.lwe_verify_opening(lctx.handle, p, one.ctypes.data, 1, None) == 0
+    lib.lwe_commitment_free(p)
     lctx.close()
