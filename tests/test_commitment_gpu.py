@@ -325,3 +325,26 @@ def test_empty_message_and_zero_length_openings(pkg, lib, oracle):
     assert lib.lwe_verify_opening(lctx.handle, p, one.ctypes.data, 1, None) == 0
     lib.lwe_commitment_free(p)
     lctx.close()
+
+
+def test_large_combination_coefficients_need_a_wide_modulus(pkg):
+    """with the 44-bit internal modulus the noise budget admits sum(c_i) up to ~2^10; a caller that
+    combines with coefficients as large as the plaintext modulus (the reference's 72-bit SEAL modulus allows that,
+    commitment.cpp:88-96) passes a 60-bit NTT prime as params->modulus, which the library honours."""
+    big = 1152921504606584833                       # 60-bit prime = 1 (mod 2^18)
+    t = 1032193
+    coeffs = [t - 1, t - 2, 777777]
+    msgs = [[1, 2, 3, 4], [5, 6, 7, 8], [9, 10, 11, 12]]
+    expect = [sum(c * m[i] for c, m in zip(coeffs, msgs)) % t for i in range(4)]
+    wide = pkg.LweContext(pkg.Params(q=big, n=4096, k=2, sigma=3.19), key_seed=5)
+    assert wide.commit_modulus == big and wide.plain_modulus == t
+    coms = [pkg.Commitment(wide, m, seed=10 + i) for i, m in enumerate(msgs)]
+    comb = pkg.Commitment.linear_combine(wide, coms, coeffs)
+    assert pkg.verify_opening_with_context(wide, comb, expect)
+    assert not pkg.verify_opening_with_context(wide, comb, [expect[0] + 1] + expect[1:])
+    wide.close()
+    narrow = pkg.LweContext(pkg.Params(q=17592186044417, n=4096, k=2, sigma=3.19), key_seed=5)
+    coms = [pkg.Commitment(narrow, m, seed=10 + i) for i, m in enumerate(msgs)]
+    small = pkg.Commitment.linear_combine(narrow, coms, [200, 300, 400])
+    assert pkg.verify_opening_with_context(narrow, small, [sum(c * m[i] for c, m in zip([200, 300, 400], msgs)) % t for i in range(4)])
+    narrow.close()
