@@ -6,12 +6,15 @@
 // into radix-16 ROUNDS of four consecutive index bits that one lane holds in 16 registers:
 //   * tile kernel   — one 256-lane workgroup owns 4096 contiguous residues (one n=4096 polynomial, or
 //     4096/n smaller ones, or one 4096-block of a larger one) and runs every round on index bits
-//     [0,12) with the tile staged in LDS between rounds (padded so that every ds_read/ds_write_b64
-//     of a round is bank-conflict free); global traffic is fully coalesced on both ends.  The 15
-//     twiddles a lane needs for round r+1 are requested before the butterflies of round r start, so
-//     their L2 latency hides behind 256 FP64 instructions.
-//   * strided round kernel — index bits >= 12 (n > 4096): 16 registers hold residues n/16 apart, all
-//     256 lanes of a workgroup walk consecutive addresses, no LDS.
+//     [0,12) with the tile staged in LDS between rounds (one pad word per 16 keeps the b64 accesses of
+//     the radix-16 rounds off each other's banks; PMC: 9 % residual conflict cycles); global traffic is
+//     fully coalesced on both ends and goes through buffer resources (SGPR base, one lane offset,
+//     immediate register offsets, hardware clipping of a partial last tile).  The 15 twiddles a lane
+//     needs for round r+1 are requested before the butterflies of round r start, so their L2 latency
+//     hides behind 256 FP64 instructions.
+//   * strided round kernel — the top 4 (n = 2^17: 5) index bits of n > 4096: 16 registers hold residues
+//     n/16 apart, all 256 lanes of a workgroup walk consecutive addresses, no LDS, twiddles are the
+//     first 15 table entries (scalar loads).
 // The intermediate array between two kernels of one transform is private, so it is left in the
 // arithmetic's raw element form (f64 bit patterns for ArithF64) — no conversion at pass boundaries.
 #pragma once
