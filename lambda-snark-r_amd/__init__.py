@@ -7,6 +7,7 @@ C-ABI are mirrored here in Python with the same names, argument meaning and erro
 * ``Commitment``  <-> rust-api/lambda-snark/src/commitment.rs:31-121 (``new``, ``clone``, ``linear_combine``, ``as_bytes``)
 * ``verify_opening_with_context`` <-> rust-api/lambda-snark/src/opening.rs:160-222
 * ``NttContext``  <-> the ``ntt_*`` symbols (only exercised by cpp-core/tests/test_ntt.cpp in the reference)
+* ``CyclicNtt`` / ``QuotientPlan`` <-> rust-api/lambda-snark/src/ntt.rs:117-233 and r1cs.rs:474-506 (prover path)
 
 All arithmetic happens in liblambda_snark_core.so (HIP, gfx950).  Nothing here computes; there is no
 CPU fallback.  (The directory name has a hyphen; load it through ``__graft_entry__.load_package()``.)
@@ -21,6 +22,7 @@ from ._abi import PROFILE_RING_B, PROFILE_SCALAR_A, LweCommitment, LweOpening, P
 __all__ = [
     "NttContext", "LweContext", "Commitment", "Params", "CoreError", "verify_opening_with_context",
     "sample_gaussian", "verify_openings_batch", "PublicParams", "PROFILE_RING_B", "PROFILE_SCALAR_A",
+    "CyclicNtt", "QuotientPlan", "compute_root_of_unity", "NTT_MODULUS", "NTT_PRIMITIVE_ROOT",
 ]
 
 
@@ -283,3 +285,110 @@ def sample_gaussian(length, sigma, seed=None, domain=16, index=0):
     if rc != 0:
         raise CoreError("sample_gaussian failed")
     return out.view(np.int64)
+
+
+# ---- prover-side polynomial path (include/lambda_snark/prover.h) -------------------------------------------------
+NTT_MODULUS = 18446744069414584321          # rust-api/lambda-snark-core/src/lib.rs:58
+NTT_PRIMITIVE_ROOT = 1753635133440165772    # lib.rs:78
+
+
+def compute_root_of_unity(n, modulus=NTT_MODULUS, primitive_root=NTT_PRIMITIVE_ROOT):
+    """rust-api/lambda-snark/src/ntt.rs:226-233 (host integer arithmetic only)."""
+    if n <= 0 or n & (n - 1) or n > 1 << 32:
+        raise ValueError("n must be power of 2, n <= 2^32")
+    return pow(primitive_root, (1 << 32) // n, modulus)
+
+
+class CyclicNtt:
+    """The transform pair of rust-api/lambda-snark/src/ntt.rs: ``forward(coeffs)`` = ``ntt_forward(coeffs, modulus, omega)``
+    (natural order in and out), ``inverse(evals)`` = ``ntt_inverse``.  One handle per (modulus, n, omega)."""
+
+    def __init__(self, n, modulus=NTT_MODULUS, omega=0, device=-1):
+        self._lib = _abi.lib()
+        self.n, self.modulus = int(n), int(modulus)
+        self._h = self._lib.lsr_cyclic_ntt_context_create(self.modulus, self.n, int(omega), device)
+        if not self._h:
+            raise CoreError(f"lsr_cyclic_ntt_context_create({modulus}, {n}) returned NULL: {_abi.last_error()}")
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def omega(self):
+        return self._lib.lsr_ntt_context_root(self._h)
+
+    def _run(self, fn, values):
+        arr = _u64_array(values).copy()
+        if arr.size % self.n:
+            raise ValueError("length must be a multiple of n")
+        if fn(self._h, arr.ctypes.data, arr.size // self.n) != 0:
+            raise CoreError("cyclic NTT failed: " + _abi.last_error())
+        return arr
+
+    def forward(self, coeffs):
+        return self._run(self._lib.lsr_cyclic_ntt_forward_batch, coeffs)
+
+    def inverse(self, evals):
+        return self._run(self._lib.lsr_cyclic_ntt_inverse_batch, evals)
+
+    def close(self):
+        if self._h:
+            self._lib.ntt_context_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class QuotientPlan:
+    """Steps 3-6 of ``R1CS::compute_quotient_poly`` (rust-api/lambda-snark/src/r1cs.rs:474-506) on the NTT path
+    (``should_use_ntt``: m a power of two, modulus NTT_MODULUS), for batches of independent instances."""
+
+    def __init__(self, m, device=-1):
+        self._lib = _abi.lib()
+        self.m = int(m)
+        self._h = self._lib.lsr_quotient_plan_create(self.m, device)
+        if not self._h:
+            raise CoreError(f"lsr_quotient_plan_create({m}) returned NULL: {_abi.last_error()}")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def quotient_batch(self, a_evals, b_evals, c_evals):
+        """-> (coefficients [batch][m], lengths [batch]); length 0 marks the reference's Err (remainder non-zero)."""
+        a, b, c = (_u64_array(v) for v in (a_evals, b_evals, c_evals))
+        if not (a.size == b.size == c.size) or a.size % self.m:
+            raise ValueError("a, b, c must hold the same number of m-word instances")
+        batch = a.size // self.m
+        quot = np.zeros((batch, self.m), dtype=np.uint64)
+        lens = np.zeros(batch, dtype=np.uint32)
+        if batch and self._lib.lsr_quotient_batch(self._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, batch, quot.ctypes.data, lens.ctypes.data) != 0:
+            raise CoreError("lsr_quotient_batch failed: " + _abi.last_error())
+        return quot, lens
+
+    def compute_quotient_poly(self, a_evals, b_evals, c_evals):
+        """One instance, with the reference's return convention: the trimmed coefficient list, or CoreError."""
+        quot, lens = self.quotient_batch(a_evals, b_evals, c_evals)
+        if lens[0] == 0:
+            raise CoreError("Polynomial division by Z_H: remainder non-zero (witness invalid)")   # r1cs.rs:1050-1054
+        return quot[0, :lens[0]].copy()
+
+    def quotient_device(self, da, db, dc, batch, dquot, dlen, stream=0):
+        if self._lib.lsr_quotient_batch_device(self._h, da, db, dc, batch, dquot, dlen, stream) != 0:
+            raise CoreError("lsr_quotient_batch_device failed: " + _abi.last_error())
+
+    def close(self):
+        if self._h:
+            self._lib.lsr_quotient_plan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

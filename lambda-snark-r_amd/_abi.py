@@ -114,6 +114,20 @@ SIGNATURES = {
     "lambda_snark_r1cs_num_variables": (u32, [vp]),
     "lsr_select_commit_modulus": (u64, [u64, u32]),
     "lsr_plain_modulus": (u64, [u32]),
+    # prover.h (cyclic NTT + quotient polynomial of the Rust prover, additive)
+    "lsr_prover_modulus": (u64, []),
+    "lsr_prover_root_2_32": (u64, []),
+    "lsr_prover_root_of_unity": (u64, [u64]),
+    "lsr_cyclic_ntt_context_create": (vp, [u64, u32, u64, c_int]),
+    "lsr_ntt_context_is_cyclic": (c_int, [vp]),
+    "lsr_cyclic_ntt_forward_batch": (c_int, [vp, vp, c_size]),
+    "lsr_cyclic_ntt_inverse_batch": (c_int, [vp, vp, c_size]),
+    "lsr_bit_reverse_device": (c_int, [vp, vp, c_int, c_size, vp]),
+    "lsr_quotient_plan_create": (vp, [u32, c_int]),
+    "lsr_quotient_plan_free": (None, [vp]),
+    "lsr_quotient_plan_size": (u32, [vp]),
+    "lsr_quotient_batch": (c_int, [vp, vp, vp, vp, c_size, vp, vp]),
+    "lsr_quotient_batch_device": (c_int, [vp, vp, vp, vp, c_size, vp, vp, vp]),
 }
 
 

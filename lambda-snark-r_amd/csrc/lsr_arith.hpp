@@ -199,6 +199,71 @@ struct ArithU64 {
     static __device__ __forceinline__ void end_of_inverse_round(elem&, const ModParams&) {}
 };
 
+// ---------------------------------------------------------------------------------------------
+// Goldilocks p = 2^64 - 2^32 + 1 — the prover's NTT field (rust-api/lambda-snark-core/src/lib.rs:58).  Above the 2^61
+// limit of the Shoup flavour; uses 2^64 = 2^32 - 1 and 2^96 = -1 (mod p).  Everything stays canonical.
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t kGoldilocks = 0xFFFFFFFF00000001ull;
+constexpr uint64_t kGoldEpsilon = 0xFFFFFFFFull;   // 2^32 - 1 = 2^64 mod p
+
+__device__ __forceinline__ uint64_t gold_add(uint64_t a, uint64_t b) {   // a, b < p
+    const uint64_t s = a + b;
+    return (s < a || s >= kGoldilocks) ? s - kGoldilocks : s;           // on carry, s - p wraps to the right residue
+}
+__device__ __forceinline__ uint64_t gold_sub(uint64_t a, uint64_t b) {
+    return a >= b ? a - b : a + kGoldilocks - b;
+}
+__device__ __forceinline__ uint64_t gold_mul(uint64_t a, uint64_t b) {
+    const unsigned __int128 wide = (unsigned __int128)a * b;
+    const uint64_t lo = (uint64_t)wide, hi = (uint64_t)(wide >> 64);
+    const uint64_t hi_hi = hi >> 32, hi_lo = hi & kGoldEpsilon;
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= kGoldEpsilon;                                   // borrow: -2^64 = -(2^32 - 1)
+    const uint64_t t1 = hi_lo * kGoldEpsilon;                             // < 2^64
+    uint64_t r = t0 + t1;
+    if (r < t0) r += kGoldEpsilon;                                        // carry: +2^64 = +(2^32 - 1)
+    return r >= kGoldilocks ? r - kGoldilocks : r;
+}
+
+struct ArithGold {
+    using elem = uint64_t;
+    using twid = uint64_t;
+
+    static __device__ __forceinline__ elem load(uint64_t x, const ModParams&) { return x >= kGoldilocks ? x - kGoldilocks : x; }
+    static __device__ __forceinline__ uint64_t store_canonical(elem v, const ModParams&) { return v; }
+    static __device__ __forceinline__ uint64_t store_reduced(elem v, const ModParams&) { return v; }
+    static __device__ __forceinline__ uint64_t store_reduced_plus(elem v, uint64_t e, const ModParams&) {
+        return gold_add(v, e >= kGoldilocks ? e - kGoldilocks : e);
+    }
+    static __device__ __forceinline__ elem pre_mul(elem v, uint64_t d, const ModParams&) { return gold_mul(v, d); }   // d < p
+    static __device__ __forceinline__ twid load_tw(const uint64_t* table, uint32_t idx) { return table[idx]; }
+    template <int COUNT>
+    static __device__ __forceinline__ void load_tw_run(rsrc_t table, uint32_t idx, twid* out) {
+        if constexpr (COUNT == 1) {
+            out[0] = buf_load64(table, idx * 8u, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < COUNT; u += 2) buf_load128(table, idx * 8u, (uint32_t)u * 8u, out[u], out[u + 1]);
+        }
+    }
+    static __device__ __forceinline__ void ct(elem& x, elem& y, twid w, const ModParams&) {
+        const uint64_t t = gold_mul(y, w), a = x;
+        x = gold_add(a, t);
+        y = gold_sub(a, t);
+    }
+    static __device__ __forceinline__ void gs(elem& x, elem& y, twid w, const ModParams&) {
+        const uint64_t a = x, b = y;
+        x = gold_add(a, b);
+        y = gold_mul(gold_sub(a, b), w);
+    }
+    static __device__ __forceinline__ void gs_scaled(elem& x, elem& y, twid w_scaled, twid n_inv, const ModParams&) {
+        const uint64_t a = x, b = y;
+        x = gold_mul(gold_add(a, b), n_inv);
+        y = gold_mul(gold_sub(a, b), w_scaled);
+    }
+    static __device__ __forceinline__ void end_of_inverse_round(elem&, const ModParams&) {}
+};
+
 // canonical (a*b) mod q for ANY 64-bit a, b (q < 2^61): 128-bit product + Barrett with floor(2^128/q)
 // (same contract as SEAL multiply_uint_mod used at ntt.cpp:117).
 __device__ __forceinline__ uint64_t mulmod_barrett128(uint64_t a, uint64_t b, const ModParams& p) {

@@ -106,6 +106,46 @@ TwiddleTables build_twiddles(uint64_t q, uint32_t n, int logn, uint64_t psi) {
     return t;
 }
 
+bool cyclic_params_valid(uint64_t q, uint32_t n, uint64_t omega, int* logn_out) {
+    if (n < 2 || n > 131072 || (n & (n - 1))) return false;
+    if (q != kProverModulus && (q >> 61)) return false;
+    if (q < 3 || (q - 1) % n != 0 || !is_prime_u64(q)) return false;
+    if (omega == 0 || omega >= q || powmod(omega, n / 2, q) != q - 1) return false;   // exact order n
+    int logn = 0;
+    while ((1u << logn) < n) ++logn;
+    if (logn_out) *logn_out = logn;
+    return true;
+}
+
+uint64_t prover_root_of_unity(uint64_t q, uint64_t n) {
+    if (q != kProverModulus || n == 0 || (n & (n - 1)) || n > (1ull << 32)) return 0;
+    return powmod(kProverRoot2_32, (1ull << 32) / n, q);
+}
+
+TwiddleTables build_cyclic_twiddles(uint64_t q, uint32_t n, int logn, uint64_t omega) {
+    TwiddleTables t;
+    t.psi = omega;
+    t.fwd.assign(n, 1);
+    t.inv.assign(n, 1);
+    std::vector<uint64_t> pw(n / 2 + 1), pw_inv(n / 2 + 1);     // omega^e, omega^-e for e <= n/2
+    const uint64_t omega_inv = invmod_prime(omega, q);
+    pw[0] = pw_inv[0] = 1;
+    for (uint32_t e = 1; e <= n / 2; ++e) {
+        pw[e] = mulmod(pw[e - 1], omega, q);
+        pw_inv[e] = mulmod(pw_inv[e - 1], omega_inv, q);
+    }
+    for (int s = 0; s < logn; ++s) {
+        const uint32_t m = 1u << s, unit = n / (2 * m);
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint32_t e = unit * bit_reverse(i, s);         // < n/2
+            t.fwd[m + i] = pw[e];
+            t.inv[m + i] = pw_inv[e];
+        }
+    }
+    t.n_inv = invmod_prime(n % q, q);
+    return t;
+}
+
 std::vector<uint64_t> gaussian_cdf(double sigma) {
     std::vector<uint64_t> cdf;
     if (!(sigma > 0.0) || !std::isfinite(sigma)) return cdf;

@@ -39,6 +39,18 @@ struct TwiddleTables {
 };
 TwiddleTables build_twiddles(uint64_t q, uint32_t n, int logn, uint64_t psi);
 
+// Cyclic transform of the prover's polynomial path (rust-api/lambda-snark/src/ntt.rs:117-201): same butterfly network,
+// other twiddles.  Entry [m + i] = omega^((n/2m) * bitrev_{log m}(i)) — group i of the m-group stage reduces modulo
+// X^(n/m) - omega^((n/m) * bitrev(i)), so its twiddle is the square root of that constant; inverse table = inverses.
+// Output of the forward network is f(omega^bitrev(i)) at slot i.
+constexpr uint64_t kProverModulus = 0xFFFFFFFF00000001ull;       // NTT_MODULUS, lambda-snark-core/src/lib.rs:58
+constexpr uint64_t kProverRoot2_32 = 1753635133440165772ull;     // NTT_PRIMITIVE_ROOT, lib.rs:78
+// n = 2^k in [2, 131072], prime q (q = NTT_MODULUS or q < 2^61), omega of exact order n.
+bool cyclic_params_valid(uint64_t q, uint32_t n, uint64_t omega, int* logn_out);
+// omega_n of compute_root_of_unity (ntt.rs:226-233); 0 unless q = NTT_MODULUS
+uint64_t prover_root_of_unity(uint64_t q, uint64_t n);
+TwiddleTables build_cyclic_twiddles(uint64_t q, uint32_t n, int logn, uint64_t omega);
+
 // Shoup quotient floor(w * 2^64 / q)
 inline uint64_t shoup_quotient(uint64_t w, uint64_t q) { return (uint64_t)(((u128)w << 64) / q); }
 

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "lambda_snark/batch.h"
 #include "lambda_snark/ntt.h"
@@ -63,29 +64,18 @@ static ModParams make_mod_params(uint64_t q, int logn) {
     return p;
 }
 
-NttContext* create_ntt_context(uint64_t q, uint32_t n, int device) {
-    int logn = 0;
-    if (!ntt_params_valid(q, n, &logn)) {
-        set_last_error("ntt_context_create: (q, n) rejected: need n = 2^k in [2,131072], prime q < 2^61, q = 1 mod 2n");
-        return nullptr;
-    }
-    const uint64_t psi = minimal_primitive_root_2n(q, n);
-    if (!psi) {
-        set_last_error("ntt_context_create: no primitive 2n-th root");
-        return nullptr;
-    }
+static NttContext* build_context(const char* where, uint64_t q, uint32_t n, int logn, int device, const TwiddleTables& tw, bool cyclic) {
     const int devices = visible_device_count();
     if (devices <= 0) {
-        set_last_error("ntt_context_create: no HIP device visible — this library has no CPU fallback");
+        set_last_error(std::string(where) + ": no HIP device visible — this library has no CPU fallback");
         std::fprintf(stderr, "lambda_snark_core: no HIP device visible; the MI355X backend has no CPU fallback\n");
         return nullptr;
     }
     if (device < 0) device = default_device();
     if (device >= devices) {
-        set_last_error("ntt_context_create: device index out of range");
+        set_last_error(std::string(where) + ": device index out of range");
         return nullptr;
     }
-    const TwiddleTables tw = build_twiddles(q, n, logn, psi);
     auto* ctx = new NttContext;
     try {
         DeviceGuard guard(device);
@@ -93,11 +83,18 @@ NttContext* create_ntt_context(uint64_t q, uint32_t n, int device) {
         ctx->degree = n;
         ctx->logn = logn;
         ctx->device = device;
-        ctx->psi = psi;
+        ctx->psi = tw.psi;
+        ctx->cyclic = cyclic;
+        ctx->gold = (q == kProverModulus);
         ctx->mod = make_mod_params(q, logn);
-        ctx->use_f64 = (q < (1ull << 45)) && arith_mode() != 1;
+        ctx->use_f64 = !ctx->gold && (q < (1ull << 45)) && arith_mode() != 1;
         const uint64_t w_last_scaled = mulmod(tw.inv[n > 1 ? 1 : 0], tw.n_inv, q);
-        if (ctx->use_f64) {
+        if (ctx->gold) {
+            ctx->fwd_gold.upload(tw.fwd);
+            ctx->inv_gold.upload(tw.inv);
+            ctx->n_inv_gold = tw.n_inv;
+            ctx->w_last_scaled_gold = w_last_scaled;
+        } else if (ctx->use_f64) {
             std::vector<double> f(n), g(n);
             for (uint32_t i = 0; i < n; ++i) {
                 f[i] = static_cast<double>(tw.fwd[i]);
@@ -121,12 +118,36 @@ NttContext* create_ntt_context(uint64_t q, uint32_t n, int device) {
         ctx->staging.allocate(3ull * n);
         LSR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     } catch (const std::exception& e) {
-        set_last_error(std::string("ntt_context_create: ") + e.what());
-        std::fprintf(stderr, "lambda_snark_core: ntt_context_create failed: %s\n", e.what());
+        set_last_error(std::string(where) + ": " + e.what());
+        std::fprintf(stderr, "lambda_snark_core: %s failed: %s\n", where, e.what());
         destroy_ntt_context(ctx);
         return nullptr;
     }
     return ctx;
+}
+
+NttContext* create_ntt_context(uint64_t q, uint32_t n, int device) {
+    int logn = 0;
+    if (!ntt_params_valid(q, n, &logn)) {
+        set_last_error("ntt_context_create: (q, n) rejected: need n = 2^k in [2,131072], prime q < 2^61, q = 1 mod 2n");
+        return nullptr;
+    }
+    const uint64_t psi = minimal_primitive_root_2n(q, n);
+    if (!psi) {
+        set_last_error("ntt_context_create: no primitive 2n-th root");
+        return nullptr;
+    }
+    return build_context("ntt_context_create", q, n, logn, device, build_twiddles(q, n, logn, psi), false);
+}
+
+NttContext* create_cyclic_ntt_context(uint64_t q, uint32_t n, uint64_t omega, int device) {
+    if (omega == 0) omega = prover_root_of_unity(q, n);
+    int logn = 0;
+    if (!cyclic_params_valid(q, n, omega, &logn)) {
+        set_last_error("lsr_cyclic_ntt_context_create: need n = 2^k in [2,131072], prime q (NTT_MODULUS or < 2^61), omega of order n");
+        return nullptr;
+    }
+    return build_context("lsr_cyclic_ntt_context_create", q, n, logn, device, build_cyclic_twiddles(q, n, logn, omega), true);
 }
 
 void destroy_ntt_context(NttContext* ctx) {
@@ -139,6 +160,8 @@ void destroy_ntt_context(NttContext* ctx) {
         ctx->inv_f64.release();
         ctx->fwd_u64.release();
         ctx->inv_u64.release();
+        ctx->fwd_gold.release();
+        ctx->inv_gold.release();
     } catch (...) {
     }
     delete ctx;
@@ -159,14 +182,28 @@ template <> struct Flavour<ArithU64> {
     static RoundConsts<ArithU64> consts(const NttContext& c) { return {c.n_inv_u64, c.w_last_scaled_u64}; }
 };
 
+template <> struct Flavour<ArithGold> {
+    static const uint64_t* fwd(const NttContext& c) { return c.fwd_gold.ptr; }
+    static const uint64_t* inv(const NttContext& c) { return c.inv_gold.ptr; }
+    static RoundConsts<ArithGold> consts(const NttContext& c) { return {c.n_inv_gold, c.w_last_scaled_gold}; }
+};
+
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 static void tile_fwd(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
     const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
     hipLaunchKernelGGL((ntt_tile_forward<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::fwd(c));
 }
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
-static void tile_inv(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* add = nullptr) {
+static void tile_inv(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* add = nullptr, const uint64_t* pre = nullptr) {
     const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
+    if constexpr (std::is_same_v<A, ArithGold> && !RAW_IN) {   // the fused diagonal multiply exists for the prover's field only
+        if (pre != nullptr) {
+            hipLaunchKernelGGL((ntt_tile_inverse<A, LT, RAW_IN, RAW_OUT, true>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::inv(c),
+                               Flavour<A>::consts(c), add, pre);
+            return;
+        }
+    }
+    if (pre != nullptr) throw std::runtime_error("pre-multiplied inverse transform: only for NTT_MODULUS contexts");
     hipLaunchKernelGGL((ntt_tile_inverse<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::inv(c),
                        Flavour<A>::consts(c), add);
 }
@@ -209,12 +246,12 @@ static void pass_forward(const NttContext& c, int lt, uint64_t* d, size_t total,
     }
 }
 template <class A>
-static void pass_inverse(const NttContext& c, int lt, uint64_t* d, size_t total, hipStream_t s) {
+static void pass_inverse(const NttContext& c, int lt, uint64_t* d, size_t total, hipStream_t s, const uint64_t* pre) {
     switch (lt) {
-        case 9: tile_inv<A, 9, false, true>(c, d, total, s); break;
-        case 10: tile_inv<A, 10, false, true>(c, d, total, s); break;
-        case 11: tile_inv<A, 11, false, true>(c, d, total, s); break;
-        default: tile_inv<A, 12, false, true>(c, d, total, s); break;
+        case 9: tile_inv<A, 9, false, true>(c, d, total, s, nullptr, pre); break;
+        case 10: tile_inv<A, 10, false, true>(c, d, total, s, nullptr, pre); break;
+        case 11: tile_inv<A, 11, false, true>(c, d, total, s, nullptr, pre); break;
+        default: tile_inv<A, 12, false, true>(c, d, total, s, nullptr, pre); break;
     }
 }
 
@@ -236,20 +273,20 @@ static void small_forward(const NttContext& c, uint64_t* d, size_t total, hipStr
     }
 }
 template <class A>
-static void small_inverse(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* add) {
+static void small_inverse(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* add, const uint64_t* pre) {
     switch (c.logn) {
-        case 1: tile_inv<A, 1, false, false>(c, d, total, s, add); break;
-        case 2: tile_inv<A, 2, false, false>(c, d, total, s, add); break;
-        case 3: tile_inv<A, 3, false, false>(c, d, total, s, add); break;
-        case 4: tile_inv<A, 4, false, false>(c, d, total, s, add); break;
-        case 5: tile_inv<A, 5, false, false>(c, d, total, s, add); break;
-        case 6: tile_inv<A, 6, false, false>(c, d, total, s, add); break;
-        case 7: tile_inv<A, 7, false, false>(c, d, total, s, add); break;
-        case 8: tile_inv<A, 8, false, false>(c, d, total, s, add); break;
-        case 9: tile_inv<A, 9, false, false>(c, d, total, s, add); break;
-        case 10: tile_inv<A, 10, false, false>(c, d, total, s, add); break;
-        case 11: tile_inv<A, 11, false, false>(c, d, total, s, add); break;
-        default: tile_inv<A, 12, false, false>(c, d, total, s, add); break;
+        case 1: tile_inv<A, 1, false, false>(c, d, total, s, add, pre); break;
+        case 2: tile_inv<A, 2, false, false>(c, d, total, s, add, pre); break;
+        case 3: tile_inv<A, 3, false, false>(c, d, total, s, add, pre); break;
+        case 4: tile_inv<A, 4, false, false>(c, d, total, s, add, pre); break;
+        case 5: tile_inv<A, 5, false, false>(c, d, total, s, add, pre); break;
+        case 6: tile_inv<A, 6, false, false>(c, d, total, s, add, pre); break;
+        case 7: tile_inv<A, 7, false, false>(c, d, total, s, add, pre); break;
+        case 8: tile_inv<A, 8, false, false>(c, d, total, s, add, pre); break;
+        case 9: tile_inv<A, 9, false, false>(c, d, total, s, add, pre); break;
+        case 10: tile_inv<A, 10, false, false>(c, d, total, s, add, pre); break;
+        case 11: tile_inv<A, 11, false, false>(c, d, total, s, add, pre); break;
+        default: tile_inv<A, 12, false, false>(c, d, total, s, add, pre); break;
     }
 }
 
@@ -265,11 +302,11 @@ static size_t ntt_chunk_bytes() {
 }
 
 template <class A>
-static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s, const uint64_t* add) {
+static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s, const uint64_t* add, const uint64_t* pre) {
     const size_t total = batch << c.logn;
     if (total == 0) return;
     if (c.logn <= kTileLog) {
-        if (inverse) small_inverse<A>(c, d, total, s, add);
+        if (inverse) small_inverse<A>(c, d, total, s, add, pre);
         else small_forward<A>(c, d, total, s);
         return;
     }
@@ -289,15 +326,19 @@ static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse
             strided<A, false, false, true>(c, base, count, c.logn - r_top, r_top, cs);
             pass_forward<A>(c, lt, base, count, cs);
         } else {
-            pass_inverse<A>(c, lt, base, count, cs);
+            pass_inverse<A>(c, lt, base, count, cs, pre);
             strided<A, true, true, false>(c, base, count, c.logn - r_top, r_top, cs, add ? add + (first << c.logn) : nullptr);
         }
     }
 }
 
-void launch_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s, const uint64_t* add_on_inverse) {
-    if (c.use_f64) run_ntt<ArithF64>(c, d, batch, inverse, s, inverse ? add_on_inverse : nullptr);
-    else run_ntt<ArithU64>(c, d, batch, inverse, s, inverse ? add_on_inverse : nullptr);
+void launch_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s, const uint64_t* add_on_inverse,
+                const uint64_t* pre_mul_on_inverse) {
+    const uint64_t* add = inverse ? add_on_inverse : nullptr;
+    const uint64_t* pre = inverse ? pre_mul_on_inverse : nullptr;
+    if (c.gold) run_ntt<ArithGold>(c, d, batch, inverse, s, add, pre);
+    else if (c.use_f64) run_ntt<ArithF64>(c, d, batch, inverse, s, add, pre);
+    else run_ntt<ArithU64>(c, d, batch, inverse, s, add, pre);
     LSR_HIP(hipGetLastError());
 }
 
@@ -305,7 +346,16 @@ void launch_pointwise(const NttContext& c, uint64_t* out, const uint64_t* a, con
     if (!count) return;
     const size_t want = (count + kThreads - 1) / kThreads;
     const unsigned grid = static_cast<unsigned>(std::min<size_t>(want, 256 * 16));
-    hipLaunchKernelGGL(pointwise_mul_kernel, dim3(grid), dim3(kThreads), 0, s, out, a, b, count, c.mod);
+    if (c.gold) hipLaunchKernelGGL(pointwise_mul_gold_kernel, dim3(grid), dim3(kThreads), 0, s, out, a, b, count);
+    else hipLaunchKernelGGL(pointwise_mul_kernel, dim3(grid), dim3(kThreads), 0, s, out, a, b, count, c.mod);
+    LSR_HIP(hipGetLastError());
+}
+
+void launch_bit_reverse(uint64_t* out, const uint64_t* in, int logn, size_t batch, hipStream_t s) {
+    const size_t total = batch << logn;
+    if (!total) return;
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 256 * 32));
+    hipLaunchKernelGGL(bit_reverse_kernel, dim3(grid), dim3(kThreads), 0, s, out, in, logn, total);
     LSR_HIP(hipGetLastError());
 }
 

@@ -47,9 +47,11 @@ __host__ __device__ constexpr uint32_t lds_slot(uint32_t idx) { return idx + (id
 template <class A> __device__ __forceinline__ uint64_t elem_bits(typename A::elem v);
 template <> __device__ __forceinline__ uint64_t elem_bits<ArithF64>(double v) { return (uint64_t)__double_as_longlong(v); }
 template <> __device__ __forceinline__ uint64_t elem_bits<ArithU64>(uint64_t v) { return v; }
+template <> __device__ __forceinline__ uint64_t elem_bits<ArithGold>(uint64_t v) { return v; }
 template <class A> __device__ __forceinline__ typename A::elem elem_from_bits(uint64_t b);
 template <> __device__ __forceinline__ double elem_from_bits<ArithF64>(uint64_t b) { return __longlong_as_double((long long)b); }
 template <> __device__ __forceinline__ uint64_t elem_from_bits<ArithU64>(uint64_t b) { return b; }
+template <> __device__ __forceinline__ uint64_t elem_from_bits<ArithGold>(uint64_t b) { return b; }
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -225,10 +227,12 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restric
 
 // `add` (optional, only when !RAW_OUT): canonical residues added to the outputs on the final store — the fused
 // discrete-Gaussian blinding add of the commitment (u = INTT(...) + e1).
-template <class A, int LT, bool RAW_IN, bool RAW_OUT>
+// PRE: every input word is first multiplied by pre[its index within the polynomial] (canonical residues) — a diagonal
+// operator fused into the read-in (the coset twist of the prover's quotient pipeline, lsr_prover.hip).
+template <class A, int LT, bool RAW_IN, bool RAW_OUT, bool PRE = false>
 __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restrict__ data, size_t total, ModParams p,
                                                                const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
-                                                               const uint64_t* __restrict__ add) {
+                                                               const uint64_t* __restrict__ add, const uint64_t* __restrict__ pre = nullptr) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
     using twid = typename A::twid;
@@ -252,8 +256,18 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
         constexpr int LO = TileRound<LT, J>::LO, R = TileRound<LT, J>::R;
         load_round_twiddles<A, LO, R, true, (NR == 1) && !RAW_OUT>(w[0], lane_base<LO, R>(t), block_pos, nmask, p.logn, table);
         uint64_t* const col = lds + lds_slot(t);
+        if constexpr (PRE) {
+            static_assert(!RAW_IN, "the fused diagonal multiply belongs to the first pass");
+            const rsrc_t diag = make_rsrc(pre, 8u << p.logn);
+            uint64_t d[kRegs];
 #pragma unroll
-        for (int k = 0; k < kRegs; ++k) col[lds_slot((uint32_t)k * kThreads)] = RAW_IN ? raw[k] : elem_bits<A>(A::load(raw[k], p));
+            for (int k = 0; k < kRegs; ++k) d[k] = buf_load64(diag, ((block_pos + t + (uint32_t)k * kThreads) & nmask) * 8u, 0);
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k) col[lds_slot((uint32_t)k * kThreads)] = elem_bits<A>(A::pre_mul(A::load(raw[k], p), d[k], p));
+        } else {
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k) col[lds_slot((uint32_t)k * kThreads)] = RAW_IN ? raw[k] : elem_bits<A>(A::load(raw[k], p));
+        }
     }
     __syncthreads();
 
@@ -384,6 +398,26 @@ static __global__ void __launch_bounds__(kThreads) pointwise_mul_kernel(uint64_t
                                                                           const uint64_t* __restrict__ b, size_t count, ModParams p) {
     const size_t stride = (size_t)gridDim.x * kThreads;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += stride) out[i] = mulmod_barrett128(a[i], b[i], p);
+}
+
+static __global__ void __launch_bounds__(kThreads) pointwise_mul_gold_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ a,
+                                                                               const uint64_t* __restrict__ b, size_t count) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    const ModParams unused{};
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += stride)
+        out[i] = gold_mul(ArithGold::load(a[i], unused), ArithGold::load(b[i], unused));
+}
+
+// out[b][i] = in[b][bitrev(i)] — boundary permutation between the natural order of rust-api/lambda-snark/src/ntt.rs and the
+// bit-reversed order the butterfly network produces/consumes
+static __global__ void __launch_bounds__(kThreads) bit_reverse_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ in, int logn,
+                                                                        size_t total) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    const uint32_t mask = (1u << logn) - 1u;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
+        const uint32_t lane = (uint32_t)i & mask;
+        out[i] = in[(i - lane) + (__brev(lane) >> (32 - logn))];
+    }
 }
 
 }  // namespace lsr

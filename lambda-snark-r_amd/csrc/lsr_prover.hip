@@ -1,0 +1,413 @@
+// Prover-side polynomial path on the NTT kernels: natural-order cyclic transforms (rust-api/lambda-snark/src/ntt.rs)
+// and the NTT-path quotient polynomial (rust-api/lambda-snark/src/r1cs.rs:474-506).  C-ABI in lambda_snark/prover.h.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "lambda_snark/prover.h"
+#include "lsr_runtime.hpp"
+
+namespace lsr {
+
+constexpr int kBlock = 256;
+
+static unsigned blocks_for(size_t work, unsigned cap = 256 * 32) {
+    return static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>((work + kBlock - 1) / kBlock, cap)));
+}
+
+__device__ __forceinline__ uint64_t gold_canon(uint64_t x) { return x >= kGoldilocks ? x - kGoldilocks : x; }
+
+// ---- quotient pipeline -------------------------------------------------------------------------------------------
+// r1cs.rs:489-503 computes N = A B - C from the interpolated polynomials and divides by Z_H = X^m - 1, failing when a
+// remainder is left.  Equivalent, with transforms of size m only:
+//   * the remainder vanishes iff N vanishes on H = {omega^k}, i.e. iff a_k b_k = c_k for every constraint k;
+//   * then Q = N / Z_H has degree <= m - 2, so it is fixed by its values on the coset psi H (psi = omega_2m, psi^2 = omega),
+//     where Z_H(psi omega^k) = psi^m - 1 = -2:   Q(psi omega^k) = (A B - C)(psi omega^k) / (-2).
+// Radix-2 in-place networks permute by bit reversal (P).  With F_w the DFT matrix of root w and a context built on the
+// CONJUGATE root omega^-1, the two launches are
+//      forward = P F_{1/omega}           : natural-order values -> m x (inverse DFT), bit-reversed
+//      inverse = (P F_{1/omega})^-1      = m^-1 F_omega P : bit-reversed coefficients -> natural-order evaluations
+// so  e --forward--> m P coeffs --[x psi^bitrev(p) fused into the read-in]--inverse--> evaluations on psi H (natural order)
+// needs no permutation and no scaling, and the way back is forward again: z = m P (psi^j Q_j)_j.  Only the m words of Q are
+// put in natural order (through LDS), multiplied there by -(2m)^-1 psi^-j.
+
+// copy the constraint evaluations into the workspace (the transforms work in place) and test a_k b_k = c_k on the way
+__global__ void __launch_bounds__(kBlock) load_check_kernel(uint64_t* __restrict__ work, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
+                                                            const uint64_t* __restrict__ c, uint32_t* __restrict__ bad, int logm, size_t per_vector) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t base = (size_t)blockIdx.x * kBlock; base < per_vector; base += stride) {   // wave-uniform trip count
+        const size_t i = base + threadIdx.x;
+        const bool live = i < per_vector;
+        bool wrong = false;
+        if (live) {
+            const uint64_t x = gold_canon(a[i]), y = gold_canon(b[i]), z = gold_canon(c[i]);
+            work[i] = x;
+            work[per_vector + i] = y;
+            work[2 * per_vector + i] = z;
+            wrong = gold_mul(x, y) != z;
+        }
+        if (logm >= 6) {   // a wavefront's 64 consecutive constraints belong to one instance
+            if (__ballot(wrong) && (threadIdx.x & 63) == 0) atomicOr(&bad[i >> logm], 1u);
+        } else if (wrong) {
+            atomicOr(&bad[i >> logm], 1u);
+        }
+    }
+}
+
+// evaluations of A B - C on the coset, written over A's
+__global__ void __launch_bounds__(kBlock) numerator_kernel(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, const uint64_t* __restrict__ c,
+                                                           size_t count) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) a[i] = gold_sub(gold_mul(a[i], b[i]), c[i]);
+}
+
+constexpr int kSplitTile = 4096;                 // quotient words per workgroup
+constexpr int kSplitPerThread = kSplitTile / kBlock;
+__device__ __forceinline__ int split_slot(int i) { return i + (i >> 6); }   // one pad word per 64
+
+// z = [instances][m] in bit-reversed order -> quotient[inst][j] = z[inst][bitrev(j)] * scale[j]  (scale[j] = -(2m)^-1 psi^-j),
+// and per instance `top` = 1 + highest non-zero index.  LOGM_HIGH: m >= 4096, one workgroup moves the 4096 words whose
+// index has a fixed middle field (bits 6..logm-7): 64-word runs on both the read and the write side.
+template <bool LOGM_HIGH>
+__global__ void __launch_bounds__(kBlock) finish_quotient_kernel(const uint64_t* __restrict__ z, const uint64_t* __restrict__ scale,
+                                                                 uint64_t* __restrict__ quotient, uint32_t* __restrict__ top, int logm, size_t total) {
+    __shared__ uint64_t tile[kSplitTile + kSplitTile / 64];
+    const int t = threadIdx.x;
+    const uint32_t mmask = (1u << logm) - 1u;
+    if constexpr (LOGM_HIGH) {
+        // bit-reversed-order index (A:6 | B | C:6)  ->  natural index (rev C | rev B | rev A)
+        const int mid_bits = logm - 12;
+        const size_t inst = blockIdx.x >> mid_bits;
+        const uint32_t B = blockIdx.x & ((1u << mid_bits) - 1u);
+        const uint32_t Brev = mid_bits ? (__brev(B) >> (32 - mid_bits)) : 0u;
+        const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+        for (int r = 0; r < kSplitPerThread; ++r) {
+            const int A = wave * kSplitPerThread + r;
+            tile[A * 65 + lane] = z[(inst << logm) + (((uint32_t)A << (logm - 6)) | (B << 6) | (uint32_t)lane)];
+        }
+        __syncthreads();
+        uint32_t best = 0;
+#pragma unroll
+        for (int r = 0; r < kSplitPerThread; ++r) {
+            const int Cout = wave * kSplitPerThread + r;              // top field of the natural index
+            const uint32_t nat = ((uint32_t)Cout << (logm - 6)) | (Brev << 6) | (uint32_t)lane;
+            const uint64_t h = gold_mul(tile[(__brev((uint32_t)lane) >> 26) * 65 + (__brev((uint32_t)Cout) >> 26)], scale[nat]);
+            quotient[(inst << logm) + nat] = h;
+            if (h != 0) best = nat + 1;                                // nat grows with r within a thread
+        }
+        for (int off = 32; off; off >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off));
+        if (best && lane == 0) atomicMax(&top[inst], best);
+    } else {
+        // m < 4096: the tile holds 2^(12-logm) whole instances; scatter into LDS, stream out in natural order
+        const size_t tile_base = (size_t)blockIdx.x * kSplitTile;
+#pragma unroll
+        for (int r = 0; r < kSplitPerThread; ++r) {
+            const int p = r * kBlock + t;
+            const size_t g = tile_base + p;
+            if (g < total) {
+                const uint32_t j = (uint32_t)p & mmask;
+                const uint32_t nat = logm ? (__brev(j) >> (32 - logm)) : 0u;
+                tile[split_slot((p & ~(int)mmask) | (int)nat)] = z[g];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kSplitPerThread; ++r) {
+            const int p = r * kBlock + t;
+            const size_t g = tile_base + p;
+            const bool live = g < total;
+            const uint32_t nat = (uint32_t)p & mmask;
+            uint64_t h = 0;
+            if (live) {
+                h = gold_mul(tile[split_slot(p)], scale[nat]);
+                quotient[g] = h;
+            }
+            if (logm >= 6) {   // a wavefront's 64 consecutive words belong to one instance: one atomic per wave
+                const uint64_t nz = __ballot(live && h != 0);
+                if (nz && (t & 63) == 63 - __clzll(nz)) atomicMax(&top[g >> logm], nat + 1);
+            } else if (live && h != 0) {
+                atomicMax(&top[g >> logm], nat + 1);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) quotient_len_kernel(uint32_t* __restrict__ len, const uint32_t* __restrict__ top,
+                                                              const uint32_t* __restrict__ bad, size_t batch) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < batch) len[i] = bad[i] ? 0u : (top[i] ? top[i] : 1u);
+}
+
+}  // namespace lsr
+
+struct LsrQuotientPlan {
+    uint32_t m = 0;
+    int logm = 0;
+    int device = 0;
+    NttContext* ntt = nullptr;                // size m, on the conjugate root omega_m^-1 (absent for m = 1)
+    lsr::DeviceBuffer<uint64_t> twist;        // psi^bitrev(p), p < m
+    lsr::DeviceBuffer<uint64_t> untwist;      // -(2m)^-1 psi^-j, j < m
+    std::mutex mutex;                         // guards the workspace and `stream`
+    lsr::DeviceBuffer<uint64_t> work;         // [3][chunk][m]
+    lsr::DeviceBuffer<uint32_t> flags;        // top[chunk], bad[chunk]
+    lsr::DeviceBuffer<uint64_t> io;           // host-API staging: evaluations in [3][chunk][m], quotient out [chunk][m]
+    lsr::DeviceBuffer<uint32_t> io_len;
+    size_t chunk = 0;
+    hipStream_t stream = nullptr;
+};
+
+namespace lsr {
+
+// instances per pass: bound the workspace (3 m words per instance; 2^26 evaluations per vector ~ 1.5 GiB).
+// LAMBDA_SNARK_QUOTIENT_CHUNK_LOG2 overrides the exponent (tests use it to force several passes).
+static size_t quotient_chunk(const LsrQuotientPlan& p, size_t batch) {
+    int log2_words = 26;
+    if (const char* e = std::getenv("LAMBDA_SNARK_QUOTIENT_CHUNK_LOG2")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 30) log2_words = v;
+    }
+    const size_t cap = std::max<size_t>(1, (size_t(1) << log2_words) >> p.logm);
+    return std::min(batch, cap);
+}
+
+static void ensure_workspace(LsrQuotientPlan& p, size_t chunk, bool host_io) {
+    if (chunk > p.chunk) {
+        p.work.allocate(3 * chunk * p.m);
+        p.flags.allocate(2 * chunk);
+        p.io.release();
+        p.io_len.release();
+        p.chunk = chunk;
+    }
+    if (host_io && p.io.count < 4 * p.chunk * p.m) {
+        p.io.allocate(4 * p.chunk * p.m);
+        p.io_len.allocate(p.chunk);
+    }
+}
+
+// one pass over `count` <= plan.chunk instances, everything on `s`
+static void quotient_pass(LsrQuotientPlan& p, const uint64_t* d_a, const uint64_t* d_b, const uint64_t* d_c, size_t count, uint64_t* d_q,
+                          uint32_t* d_len, hipStream_t s) {
+    const size_t per_vector = count << p.logm;
+    uint64_t* work = p.work.ptr;
+    uint32_t* top = p.flags.ptr;
+    uint32_t* bad = p.flags.ptr + count;
+    LSR_HIP(hipMemsetAsync(p.flags.ptr, 0, 2 * count * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(load_check_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, d_a, d_b, d_c, bad, p.logm, per_vector);
+    if (p.ntt) {
+        launch_ntt(*p.ntt, work, 3 * count, false, s);                                   // interpolation: r1cs.rs:489-491
+        launch_ntt(*p.ntt, work, 3 * count, true, s, nullptr, p.twist.ptr);              // evaluation on the coset psi H
+        hipLaunchKernelGGL(numerator_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, work + per_vector, work + 2 * per_vector,
+                           per_vector);                                                  // r1cs.rs:495-499, pointwise
+        launch_ntt(*p.ntt, work, count, false, s);                                       // back to (twisted, bit-reversed) coefficients
+        if (p.logm >= 12) {
+            hipLaunchKernelGGL(finish_quotient_kernel<true>, dim3(static_cast<unsigned>(per_vector / kSplitTile)), dim3(kBlock), 0, s, work,
+                               p.untwist.ptr, d_q, top, p.logm, per_vector);
+        } else {
+            hipLaunchKernelGGL(finish_quotient_kernel<false>, dim3(static_cast<unsigned>((per_vector + kSplitTile - 1) / kSplitTile)), dim3(kBlock), 0, s,
+                               work, p.untwist.ptr, d_q, top, p.logm, per_vector);
+        }
+    } else {
+        LSR_HIP(hipMemsetAsync(d_q, 0, per_vector * 8, s));                              // m = 1: constants, Q = 0 when a b = c
+    }
+    hipLaunchKernelGGL(quotient_len_kernel, dim3(blocks_for(count, ~0u)), dim3(kBlock), 0, s, d_len, top, bad, count);
+    LSR_HIP(hipGetLastError());
+}
+
+static void quotient_device(LsrQuotientPlan& p, const uint64_t* d_a, const uint64_t* d_b, const uint64_t* d_c, size_t batch, uint64_t* d_q,
+                            uint32_t* d_len, hipStream_t s) {
+    DeviceGuard guard(p.device);
+    std::lock_guard<std::mutex> lock(p.mutex);
+    const size_t chunk = quotient_chunk(p, batch);
+    ensure_workspace(p, chunk, false);
+    for (size_t done = 0; done < batch; done += chunk) {
+        const size_t now = std::min(chunk, batch - done);
+        const size_t off = done << p.logm;
+        quotient_pass(p, d_a + off, d_b + off, d_c + off, now, d_q + off, d_len + done, s);
+    }
+}
+
+static void quotient_host(LsrQuotientPlan& p, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t batch, uint64_t* q, uint32_t* len) {
+    DeviceGuard guard(p.device);
+    std::lock_guard<std::mutex> lock(p.mutex);
+    const size_t chunk = quotient_chunk(p, batch);
+    ensure_workspace(p, chunk, true);
+    const size_t slot = p.chunk << p.logm;
+    for (size_t done = 0; done < batch; done += chunk) {
+        const size_t now = std::min(chunk, batch - done);
+        const size_t off = done << p.logm, bytes = (now << p.logm) * 8;
+        LSR_HIP(hipMemcpyAsync(p.io.ptr, a + off, bytes, hipMemcpyHostToDevice, p.stream));
+        LSR_HIP(hipMemcpyAsync(p.io.ptr + slot, b + off, bytes, hipMemcpyHostToDevice, p.stream));
+        LSR_HIP(hipMemcpyAsync(p.io.ptr + 2 * slot, c + off, bytes, hipMemcpyHostToDevice, p.stream));
+        quotient_pass(p, p.io.ptr, p.io.ptr + slot, p.io.ptr + 2 * slot, now, p.io.ptr + 3 * slot, p.io_len.ptr, p.stream);
+        LSR_HIP(hipMemcpyAsync(q + off, p.io.ptr + 3 * slot, bytes, hipMemcpyDeviceToHost, p.stream));
+        LSR_HIP(hipMemcpyAsync(len + done, p.io_len.ptr, now * sizeof(uint32_t), hipMemcpyDeviceToHost, p.stream));
+        LSR_HIP(hipStreamSynchronize(p.stream));
+    }
+}
+
+static void destroy_plan(LsrQuotientPlan* p) {
+    if (!p) return;
+    try {
+        DeviceGuard guard(p->device);
+        if (p->stream) (void)hipStreamDestroy(p->stream);
+        p->work.release();
+        p->flags.release();
+        p->io.release();
+        p->io_len.release();
+        p->twist.release();
+        p->untwist.release();
+    } catch (...) {
+    }
+    destroy_ntt_context(p->ntt);
+    delete p;
+}
+
+static LsrQuotientPlan* create_plan(uint32_t m, int device) {
+    if (m == 0 || m > 131072 || (m & (m - 1))) {
+        set_last_error("lsr_quotient_plan_create: m must be a power of two in [1, 131072] (r1cs.rs:386-389)");
+        return nullptr;
+    }
+    const int devices = visible_device_count();
+    if (devices <= 0) {
+        set_last_error("lsr_quotient_plan_create: no HIP device visible — this library has no CPU fallback");
+        std::fprintf(stderr, "lambda_snark_core: no HIP device visible; the MI355X backend has no CPU fallback\n");
+        return nullptr;
+    }
+    if (device < 0) device = default_device();
+    if (device >= devices) {
+        set_last_error("lsr_quotient_plan_create: device index out of range");
+        return nullptr;
+    }
+    auto* p = new LsrQuotientPlan;
+    p->m = m;
+    p->device = device;
+    while ((1u << p->logm) < m) ++p->logm;
+    const uint64_t q = kProverModulus;
+    if (m >= 2) {
+        p->ntt = create_cyclic_ntt_context(q, m, invmod_prime(prover_root_of_unity(q, m), q), device);
+        if (!p->ntt) {
+            delete p;
+            return nullptr;
+        }
+    }
+    try {
+        DeviceGuard guard(device);
+        if (m >= 2) {
+            const uint64_t psi = prover_root_of_unity(q, 2ull * m), psi_inv = invmod_prime(psi, q);
+            std::vector<uint64_t> twist(m), untwist(m);
+            uint64_t up = 1, down = q - invmod_prime((2ull * m) % q, q);   // -(2m)^-1
+            for (uint32_t j = 0; j < m; ++j) {
+                twist[bit_reverse(j, p->logm)] = up;
+                untwist[j] = down;
+                up = mulmod(up, psi, q);
+                down = mulmod(down, psi_inv, q);
+            }
+            p->twist.upload(twist);
+            p->untwist.upload(untwist);
+        }
+        LSR_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    } catch (const std::exception& e) {
+        set_last_error(std::string("lsr_quotient_plan_create: ") + e.what());
+        destroy_plan(p);
+        return nullptr;
+    }
+    return p;
+}
+
+// natural-order transforms for host callers: ntt.rs:117-201
+static void cyclic_host(const NttContext& c, uint64_t* values, size_t batch, bool inverse) {
+    DeviceGuard guard(c.device);
+    const size_t n = c.degree;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, (256ull << 20) / (n * 8)));
+    DeviceBuffer<uint64_t> x(chunk * n), y(chunk * n);
+    std::lock_guard<std::mutex> lock(c.staging_mutex);   // serialises use of c.stream
+    for (size_t done = 0; done < batch; done += chunk) {
+        const size_t now = std::min(chunk, batch - done);
+        LSR_HIP(hipMemcpyAsync(x.ptr, values + done * n, now * n * 8, hipMemcpyHostToDevice, c.stream));
+        if (inverse) {
+            launch_bit_reverse(y.ptr, x.ptr, c.logn, now, c.stream);
+            launch_ntt(c, y.ptr, now, true, c.stream);
+        } else {
+            launch_ntt(c, x.ptr, now, false, c.stream);
+            launch_bit_reverse(y.ptr, x.ptr, c.logn, now, c.stream);
+        }
+        LSR_HIP(hipMemcpyAsync(values + done * n, y.ptr, now * n * 8, hipMemcpyDeviceToHost, c.stream));
+        LSR_HIP(hipStreamSynchronize(c.stream));
+    }
+}
+
+}  // namespace lsr
+
+using lsr::set_last_error;
+
+template <class F>
+static int guarded(const char* where, F&& body) noexcept {
+    try {
+        body();
+        return 0;
+    } catch (const std::exception& e) {
+        set_last_error(std::string(where) + ": " + e.what());
+        std::fprintf(stderr, "lambda_snark_core: %s failed: %s\n", where, e.what());
+        return -1;
+    } catch (...) {
+        set_last_error(std::string(where) + ": unknown exception");
+        return -1;
+    }
+}
+
+extern "C" {
+
+uint64_t lsr_prover_modulus(void) noexcept { return lsr::kProverModulus; }
+uint64_t lsr_prover_root_2_32(void) noexcept { return lsr::kProverRoot2_32; }
+uint64_t lsr_prover_root_of_unity(uint64_t n) noexcept { return lsr::prover_root_of_unity(lsr::kProverModulus, n); }
+
+NttContext* lsr_cyclic_ntt_context_create(uint64_t q, uint32_t n, uint64_t omega, int device) noexcept {
+    try {
+        return lsr::create_cyclic_ntt_context(q, n, omega, device);
+    } catch (...) {
+        return nullptr;
+    }
+}
+int lsr_ntt_context_is_cyclic(const NttContext* ctx) noexcept { return ctx && ctx->cyclic ? 1 : 0; }
+
+int lsr_cyclic_ntt_forward_batch(const NttContext* ctx, uint64_t* values, size_t batch) noexcept {
+    if (!ctx || !values || !ctx->cyclic) return -1;
+    if (batch == 0) return 0;
+    return guarded("lsr_cyclic_ntt_forward_batch", [&] { lsr::cyclic_host(*ctx, values, batch, false); });
+}
+int lsr_cyclic_ntt_inverse_batch(const NttContext* ctx, uint64_t* values, size_t batch) noexcept {
+    if (!ctx || !values || !ctx->cyclic) return -1;
+    if (batch == 0) return 0;
+    return guarded("lsr_cyclic_ntt_inverse_batch", [&] { lsr::cyclic_host(*ctx, values, batch, true); });
+}
+int lsr_bit_reverse_device(uint64_t* d_out, const uint64_t* d_in, int logn, size_t batch, void* stream) noexcept {
+    if (!d_out || !d_in || d_out == d_in || logn < 1 || logn > 31) return -1;
+    return guarded("lsr_bit_reverse_device", [&] { lsr::launch_bit_reverse(d_out, d_in, logn, batch, static_cast<hipStream_t>(stream)); });
+}
+
+LsrQuotientPlan* lsr_quotient_plan_create(uint32_t m, int device) noexcept {
+    try {
+        return lsr::create_plan(m, device);
+    } catch (...) {
+        return nullptr;
+    }
+}
+void lsr_quotient_plan_free(LsrQuotientPlan* plan) noexcept { lsr::destroy_plan(plan); }
+uint32_t lsr_quotient_plan_size(const LsrQuotientPlan* plan) noexcept { return plan ? plan->m : 0; }
+
+int lsr_quotient_batch(LsrQuotientPlan* plan, const uint64_t* a_evals, const uint64_t* b_evals, const uint64_t* c_evals, size_t batch,
+                       uint64_t* quotient, uint32_t* quotient_len) noexcept {
+    if (!plan || !a_evals || !b_evals || !c_evals || !quotient || !quotient_len) return -1;
+    if (batch == 0) return 0;
+    return guarded("lsr_quotient_batch", [&] { lsr::quotient_host(*plan, a_evals, b_evals, c_evals, batch, quotient, quotient_len); });
+}
+int lsr_quotient_batch_device(LsrQuotientPlan* plan, const uint64_t* d_a, const uint64_t* d_b, const uint64_t* d_c, size_t batch, uint64_t* d_quotient,
+                              uint32_t* d_quotient_len, void* stream) noexcept {
+    if (!plan || !d_a || !d_b || !d_c || !d_quotient || !d_quotient_len) return -1;
+    if (batch == 0) return 0;
+    return guarded("lsr_quotient_batch_device",
+                   [&] { lsr::quotient_device(*plan, d_a, d_b, d_c, batch, d_quotient, d_quotient_len, static_cast<hipStream_t>(stream)); });
+}
+
+}  // extern "C"

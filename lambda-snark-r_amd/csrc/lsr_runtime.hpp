@@ -80,11 +80,15 @@ struct NttContext {
     int logn = 0;
     int device = 0;
     bool use_f64 = false;
+    bool gold = false;       // modulus = NTT_MODULUS (2^64 - 2^32 + 1): ArithGold kernels
+    bool cyclic = false;     // cyclic twiddle tables (prover path) instead of negacyclic; psi then holds omega
     uint64_t psi = 0;
     lsr::ModParams mod{};
     // stage-order twiddles on the device; only the flavour in use is populated
     lsr::DeviceBuffer<double> fwd_f64, inv_f64;
     lsr::DeviceBuffer<lsr::ShoupOperand> fwd_u64, inv_u64;
+    lsr::DeviceBuffer<uint64_t> fwd_gold, inv_gold;
+    uint64_t n_inv_gold = 0, w_last_scaled_gold = 0;
     double n_inv_f64 = 0, w_last_scaled_f64 = 0;
     lsr::ShoupOperand n_inv_u64{}, w_last_scaled_u64{};
     // staging for the single-polynomial host-pointer entry points
@@ -96,14 +100,20 @@ struct NttContext {
 namespace lsr {
 
 NttContext* create_ntt_context(uint64_t q, uint32_t n, int device);
+// cyclic transform over F_q with the given primitive n-th root (0 = the reference's root for NTT_MODULUS)
+NttContext* create_cyclic_ntt_context(uint64_t q, uint32_t n, uint64_t omega, int device);
 void destroy_ntt_context(NttContext* ctx);
 // asynchronous launches on `stream`, data resident on ctx->device
 // add_on_inverse (optional): canonical residues [batch][n] added to the outputs of an inverse transform in its final
 // store (the commitment's fused blinding add)
+// pre_mul_on_inverse (optional, NTT_MODULUS contexts): canonical residues [n]; input word i of every polynomial of an
+// inverse transform is multiplied by entry i as it is read
 void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inverse, hipStream_t stream,
-                const uint64_t* add_on_inverse = nullptr);
+                const uint64_t* add_on_inverse = nullptr, const uint64_t* pre_mul_on_inverse = nullptr);
 void launch_pointwise(const NttContext& ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t count,
                       hipStream_t stream);
+// out[b][i] = in[b][bitrev_logn(i)] (out != in)
+void launch_bit_reverse(uint64_t* d_out, const uint64_t* d_in, int logn, size_t batch, hipStream_t stream);
 int arith_mode();
 
 }  // namespace lsr

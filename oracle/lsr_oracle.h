@@ -98,6 +98,17 @@ void oracle_lwe_public_matrix(const oracle_lwe* c, uint64_t* a_hat);
 void oracle_mlwe_matvec(const oracle_ntt* t, uint32_t k, const uint64_t* a_hat, const uint64_t* r,
                         const uint64_t* e1, uint64_t* u);
 
+/* ---------- prover-side polynomial path (lsr_prover_oracle.c; rust-api/lambda-snark/src/{ntt,r1cs}.rs) ---------- */
+uint64_t oracle_prover_modulus(void);
+uint64_t oracle_prover_root_2_32(void);
+uint64_t oracle_root_of_unity(uint64_t n, uint64_t q, uint64_t root_2_32);
+int      oracle_cyclic_ntt_forward(uint64_t* data, size_t n, uint64_t q, uint64_t omega);
+int      oracle_cyclic_ntt_inverse(uint64_t* data, size_t n, uint64_t q, uint64_t omega);
+void     oracle_cyclic_ntt_naive(const uint64_t* in, uint64_t* out, size_t n, uint64_t q, uint64_t omega);
+uint64_t oracle_eval_poly(const uint64_t* poly, size_t len, uint64_t x, uint64_t q);
+size_t   oracle_quotient_ntt_path(const uint64_t* a_evals, const uint64_t* b_evals, const uint64_t* c_evals, size_t m,
+                                  uint64_t q, uint64_t root_2_32, uint64_t* quotient);
+
 #ifdef __cplusplus
 }
 #endif

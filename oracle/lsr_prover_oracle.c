@@ -1,0 +1,155 @@
+/*
+ * lsr_prover_oracle.c — CPU oracle for the prover-side polynomial path.
+ *
+ * TEST INFRASTRUCTURE ONLY (same rule as lsr_oracle.h).
+ *
+ * Restates, with its own loops, the behaviour of
+ *   - rust-api/lambda-snark/src/ntt.rs:117-201   cyclic radix-2 NTT over F_q, natural order in and out,
+ *                                                 inverse = transform with omega^-1 then scale by n^-1
+ *   - rust-api/lambda-snark/src/ntt.rs:226-233   compute_root_of_unity: root^(2^32 / n)
+ *   - rust-api/lambda-snark/src/r1cs.rs:474-506  compute_quotient_poly on the NTT path (steps 3-6)
+ *   - rust-api/lambda-snark/src/r1cs.rs:846-863  poly_mul (schoolbook), :876-893 poly_sub (trims),
+ *     :959-969 vanishing_poly (X^m - 1), :995-1064 poly_div_vanishing (long division, trims, Err on remainder)
+ *   - rust-api/lambda-snark-core/src/lib.rs:58,78 NTT_MODULUS / NTT_PRIMITIVE_ROOT
+ *
+ * PINNED by the reference's own tests: ntt.rs:264-339 (root hierarchy, the 2/4/8-point known answers,
+ * round trips for n = 2..1024), ntt.rs:341-372 (linearity), lambda-snark-core/src/lib.rs:313-375 (modulus and
+ * root properties) — replayed in tests/test_prover_oracle.py; plus the definition out[k] = f(omega^k)
+ * evaluated independently in O(n^2).  The quotient has no known-answer vector in the reference for the NTT
+ * modulus; it is pinned by the identity the reference tests check (r1cs.rs:1723-1777):
+ * Q(alpha) * Z_H(alpha) = A(alpha) B(alpha) - C(alpha).
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "lsr_oracle.h"
+
+static uint64_t addm(uint64_t a, uint64_t b, uint64_t q) {
+    unsigned __int128 s = (unsigned __int128)a + b;
+    return (uint64_t)(s >= q ? s - q : s);
+}
+static uint64_t subm(uint64_t a, uint64_t b, uint64_t q) {
+    unsigned __int128 d = (unsigned __int128)a + q - b;
+    return (uint64_t)(d >= q ? d - q : d);
+}
+
+uint64_t oracle_prover_modulus(void) { return 18446744069414584321ull; }       /* lib.rs:58 */
+uint64_t oracle_prover_root_2_32(void) { return 1753635133440165772ull; }       /* lib.rs:78 */
+
+uint64_t oracle_root_of_unity(uint64_t n, uint64_t q, uint64_t root_2_32) {      /* ntt.rs:226-233 */
+    if (n == 0 || (n & (n - 1)) || n > (1ull << 32)) return 0;
+    return oracle_powmod(root_2_32, (1ull << 32) / n, q);
+}
+
+static size_t reverse_index(size_t x, int bits) {
+    size_t r = 0;
+    for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
+/* ntt.rs:117-163 — decimation in time: permute, then log n butterfly levels with omega^(n/span) */
+int oracle_cyclic_ntt_forward(uint64_t* data, size_t n, uint64_t q, uint64_t omega) {
+    if (n == 0 || (n & (n - 1))) return -1;
+    if (n == 1) return 0;
+    int bits = 0;
+    while (((size_t)1 << bits) < n) ++bits;
+    for (size_t i = 0; i < n; ++i) {
+        size_t j = reverse_index(i, bits);
+        if (i < j) { uint64_t t = data[i]; data[i] = data[j]; data[j] = t; }
+    }
+    for (int level = 1; level <= bits; ++level) {
+        size_t span = (size_t)1 << level, half = span >> 1;
+        uint64_t step = oracle_powmod(omega, n / span, q);
+        for (size_t start = 0; start < n; start += span) {
+            uint64_t w = 1;
+            for (size_t j = 0; j < half; ++j) {
+                uint64_t hi = oracle_mulmod(data[start + j + half], w, q);
+                uint64_t lo = data[start + j];
+                data[start + j] = addm(lo, hi, q);
+                data[start + j + half] = subm(lo, hi, q);
+                w = oracle_mulmod(w, step, q);
+            }
+        }
+    }
+    return 0;
+}
+
+/* ntt.rs:183-201 */
+int oracle_cyclic_ntt_inverse(uint64_t* data, size_t n, uint64_t q, uint64_t omega) {
+    if (n == 0 || (n & (n - 1))) return -1;
+    if (n == 1) return 0;
+    uint64_t omega_inv = oracle_powmod(omega, q - 2, q);
+    if (oracle_cyclic_ntt_forward(data, n, q, omega_inv) != 0) return -1;
+    uint64_t n_inv = oracle_powmod((uint64_t)n % q, q - 2, q);
+    for (size_t i = 0; i < n; ++i) data[i] = oracle_mulmod(data[i], n_inv, q);
+    return 0;
+}
+
+/* the definition the transform must satisfy: out[k] = sum_i f_i omega^(ik) */
+void oracle_cyclic_ntt_naive(const uint64_t* in, uint64_t* out, size_t n, uint64_t q, uint64_t omega) {
+    for (size_t k = 0; k < n; ++k) {
+        uint64_t x = oracle_powmod(omega, k, q), acc = 0, p = 1;
+        for (size_t i = 0; i < n; ++i) {
+            acc = addm(acc, oracle_mulmod(in[i] % q, p, q), q);
+            p = oracle_mulmod(p, x, q);
+        }
+        out[k] = acc;
+    }
+}
+
+uint64_t oracle_eval_poly(const uint64_t* poly, size_t len, uint64_t x, uint64_t q) {   /* r1cs.rs:362-373 */
+    uint64_t acc = 0, p = 1;
+    for (size_t i = 0; i < len; ++i) {
+        acc = addm(acc, oracle_mulmod(poly[i] % q, p, q), q);
+        p = oracle_mulmod(p, x % q, q);
+    }
+    return acc;
+}
+
+/*
+ * Quotient on the NTT path, restating r1cs.rs:489-503 with m a power of two and q = NTT_MODULUS:
+ *   interpolate A, B, C over {omega^i} (inverse NTT), multiply A*B (schoolbook), subtract C, trim,
+ *   divide by X^m - 1 by long division.  quotient must hold m words.
+ * Returns the trimmed quotient length (>= 1), or 0 when the division leaves a remainder (the reference's Err).
+ */
+size_t oracle_quotient_ntt_path(const uint64_t* a_evals, const uint64_t* b_evals, const uint64_t* c_evals, size_t m,
+                                uint64_t q, uint64_t root_2_32, uint64_t* quotient) {
+    if (m == 0 || (m & (m - 1))) return 0;
+    const uint64_t omega = oracle_root_of_unity(m, q, root_2_32);
+    uint64_t* a = malloc(m * 8); uint64_t* b = malloc(m * 8); uint64_t* c = malloc(m * 8);
+    size_t prod_len = 2 * m - 1;
+    uint64_t* num = calloc(prod_len, 8);
+    memcpy(a, a_evals, m * 8); memcpy(b, b_evals, m * 8); memcpy(c, c_evals, m * 8);
+    oracle_cyclic_ntt_inverse(a, m, q, omega);
+    oracle_cyclic_ntt_inverse(b, m, q, omega);
+    oracle_cyclic_ntt_inverse(c, m, q, omega);
+    for (size_t i = 0; i < m; ++i)                                   /* poly_mul */
+        for (size_t j = 0; j < m; ++j)
+            num[i + j] = addm(num[i + j], oracle_mulmod(a[i] % q, b[j] % q, q), q);
+    size_t num_len = prod_len;                                       /* poly_sub: max(len) then trim */
+    for (size_t i = 0; i < num_len; ++i) num[i] = subm(num[i] % q, i < m ? c[i] % q : 0, q);
+    while (num_len > 1 && num[num_len - 1] == 0) --num_len;
+    size_t result = 0;
+    memset(quotient, 0, m * 8);
+    if (num_len - 1 < m) {                                           /* degree below deg(Z_H) */
+        int all_zero = 1;
+        for (size_t i = 0; i < num_len; ++i) all_zero &= (num[i] == 0);
+        result = all_zero ? 1 : 0;                                   /* Ok([0]) or Err */
+    } else {
+        size_t deg_quot = num_len - 1 - m;
+        for (size_t i = deg_quot + 1; i-- > 0;) {                    /* long division by X^m - 1 (monic) */
+            uint64_t coef = num[i + m] % q;
+            quotient[i] = coef;
+            num[i] = subm(num[i], oracle_mulmod(coef, q - 1, q), q); /* - coef * (-1) */
+            num[i + m] = subm(num[i + m], coef, q);                  /* - coef * 1    */
+        }
+        int clean = 1;
+        for (size_t i = 0; i < num_len; ++i) clean &= (num[i] == 0);
+        if (clean) {
+            result = deg_quot + 1;
+            while (result > 1 && quotient[result - 1] == 0) --result;
+        }
+    }
+    free(a); free(b); free(c); free(num);
+    return result;
+}

@@ -47,6 +47,14 @@ class Oracle:
         L.oracle_lwe_linear_combine.restype = ci; L.oracle_lwe_linear_combine.argtypes = [vp, vp, vp, vp, sz, vp]
         L.oracle_lwe_public_matrix.argtypes = [vp, vp]
         L.oracle_mlwe_matvec.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.oracle_prover_modulus.restype = u64; L.oracle_prover_modulus.argtypes = []
+        L.oracle_prover_root_2_32.restype = u64; L.oracle_prover_root_2_32.argtypes = []
+        L.oracle_root_of_unity.restype = u64; L.oracle_root_of_unity.argtypes = [u64, u64, u64]
+        L.oracle_cyclic_ntt_forward.restype = ci; L.oracle_cyclic_ntt_forward.argtypes = [vp, sz, u64, u64]
+        L.oracle_cyclic_ntt_inverse.restype = ci; L.oracle_cyclic_ntt_inverse.argtypes = [vp, sz, u64, u64]
+        L.oracle_cyclic_ntt_naive.argtypes = [vp, vp, sz, u64, u64]
+        L.oracle_eval_poly.restype = u64; L.oracle_eval_poly.argtypes = [vp, sz, u64, u64]
+        L.oracle_quotient_ntt_path.restype = sz; L.oracle_quotient_ntt_path.argtypes = [vp, vp, vp, sz, u64, u64, vp]
         self._ntt = {}
         self._lwe = {}
 
@@ -168,6 +176,44 @@ class Oracle:
         u = np.zeros(k * n, dtype=np.uint64)
         self.L.oracle_mlwe_matvec(self.ntt_handle(q, n), k, a_hat.ctypes.data, r.ctypes.data, e1p, u.ctypes.data)
         return u.reshape(k, n)
+
+
+    # ---- prover-side polynomial path (rust-api/lambda-snark/src/{ntt,r1cs}.rs) ----
+    @property
+    def prover_q(self):
+        return self.L.oracle_prover_modulus()
+
+    def prover_omega(self, n, q=None):
+        return self.L.oracle_root_of_unity(n, q or self.prover_q, self.L.oracle_prover_root_2_32())
+
+    def cyclic_forward(self, values, q, omega):
+        a = np.ascontiguousarray(values, dtype=np.uint64).copy()
+        assert self.L.oracle_cyclic_ntt_forward(a.ctypes.data, a.size, q, omega) == 0
+        return a
+
+    def cyclic_inverse(self, values, q, omega):
+        a = np.ascontiguousarray(values, dtype=np.uint64).copy()
+        assert self.L.oracle_cyclic_ntt_inverse(a.ctypes.data, a.size, q, omega) == 0
+        return a
+
+    def cyclic_naive(self, values, q, omega):
+        a = np.ascontiguousarray(values, dtype=np.uint64)
+        out = np.zeros_like(a)
+        self.L.oracle_cyclic_ntt_naive(a.ctypes.data, out.ctypes.data, a.size, q, omega)
+        return out
+
+    def eval_poly(self, poly, x, q):
+        a = np.ascontiguousarray(poly, dtype=np.uint64)
+        return self.L.oracle_eval_poly(a.ctypes.data, a.size, x, q)
+
+    def quotient(self, a_evals, b_evals, c_evals):
+        """-> (coefficients padded to m words, trimmed length; 0 = remainder non-zero)"""
+        a = np.ascontiguousarray(a_evals, dtype=np.uint64); b = np.ascontiguousarray(b_evals, dtype=np.uint64)
+        c = np.ascontiguousarray(c_evals, dtype=np.uint64)
+        out = np.zeros(a.size, dtype=np.uint64)
+        ln = self.L.oracle_quotient_ntt_path(a.ctypes.data, b.ctypes.data, c.ctypes.data, a.size, self.prover_q,
+                                             self.L.oracle_prover_root_2_32(), out.ctypes.data)
+        return out, ln
 
 
 _cached = None

@@ -1,0 +1,239 @@
+"""GPU parity tests for the prover-side polynomial path (include/lambda_snark/prover.h), through the C-ABI.
+First rust-api/lambda-snark/src/ntt.rs's own tests restated, then bit-exact parity with the oracle over every
+size and arithmetic flavour, then the NTT-path quotient of r1cs.rs:474-506."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+Q = 18446744069414584321
+Q44 = 17592169062401        # has 2^13-th roots of unity (r1cs.rs:534-547)
+Q60 = 1152921504606584833   # = 1 mod 2^18
+
+
+def root_of_order(q, n):
+    """some primitive n-th root of unity mod prime q (n a power of two)"""
+    g = 2
+    while True:
+        w = pow(g, (q - 1) // n, q)
+        if n == 1 or pow(w, n // 2, q) == q - 1:
+            return w
+        g += 1
+
+
+# ---- rust-api/lambda-snark/src/ntt.rs tests --------------------------------------------------------------------
+def test_ntt_2_point(pkg):
+    t = pkg.CyclicNtt(2)
+    assert t.omega == Q - 1 == pkg.compute_root_of_unity(2)       # ntt.rs:266-270
+    ev = t.forward([1, 2])
+    assert list(ev) == [3, Q - 1]                                  # ntt.rs:293-296
+    assert list(t.inverse(ev)) == [1, 2]
+
+
+def test_ntt_4_and_8_point(pkg):
+    t = pkg.CyclicNtt(4)
+    ev = t.forward([1, 2, 3, 4])
+    assert ev[0] == 10                                             # ntt.rs:312
+    assert list(t.inverse(ev)) == [1, 2, 3, 4]
+    t = pkg.CyclicNtt(8)
+    ev = t.forward([1, 2, 3, 4, 5, 6, 7, 8])
+    assert ev[0] == 36                                             # ntt.rs:327
+    assert list(t.inverse(ev)) == [1, 2, 3, 4, 5, 6, 7, 8]
+
+
+def test_ntt_inverse_correctness(pkg, oracle):
+    for log_n in range(1, 11):                                     # ntt.rs:341-355
+        n = 1 << log_n
+        t = pkg.CyclicNtt(n)
+        assert t.omega == oracle.prover_omega(n)
+        coeffs = np.array([(i * 123456789) % Q for i in range(n)], dtype=np.uint64)
+        ev = t.forward(coeffs)
+        assert np.array_equal(ev, oracle.cyclic_forward(coeffs, Q, t.omega))
+        assert np.array_equal(t.inverse(ev), coeffs)
+        t.close()
+
+
+def test_ntt_linearity(pkg):
+    t = pkg.CyclicNtt(4)                                           # ntt.rs:357-389
+    f, g, a, b = [1, 2, 3, 4], [5, 6, 7, 8], 3, 7
+    combo = [(a * x + b * y) % Q for x, y in zip(f, g)]
+    nf, ng = t.forward(f), t.forward(g)
+    assert [int(v) for v in t.forward(combo)] == [(a * int(x) + b * int(y)) % Q for x, y in zip(nf, ng)]
+
+
+# ---- parity with the oracle -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("log_n", list(range(1, 18)))
+def test_goldilocks_parity_all_sizes(pkg, oracle, log_n):
+    n = 1 << log_n
+    batch = 5 if log_n <= 12 else 3
+    t = pkg.CyclicNtt(n)
+    rng = np.random.default_rng(100 + log_n)
+    x = rng.integers(0, Q, size=(batch, n), dtype=np.uint64)
+    x[0, 0] = Q - 1; x[0, 1] = 0; x[-1, -1] = Q - 1; x[1 % batch, :8] = Q - 1
+    ev = t.forward(x)
+    want = np.stack([oracle.cyclic_forward(row, Q, t.omega) for row in x])
+    assert np.array_equal(ev, want)
+    assert np.array_equal(t.inverse(ev), x)
+    back = np.stack([oracle.cyclic_inverse(row, Q, t.omega) for row in x])
+    assert np.array_equal(t.inverse(x), back)
+    t.close()
+
+
+def test_goldilocks_extreme_values(pkg, oracle):
+    """all-(q-1) and 2^32-structured inputs stress the carry/borrow paths of the 2^64 = 2^32 - 1 reduction"""
+    for n in [8, 4096, 65536]:
+        t = pkg.CyclicNtt(n)
+        rng = np.random.default_rng(n)
+        pool = np.array([0, 1, Q - 1, Q - 2, 2**32, 2**32 - 1, 2**32 + 1, Q - 2**32, 2**63, 2**63 + 1, Q // 2, 0xFFFFFFFF00000000], dtype=np.uint64)
+        x = np.stack([np.full(n, Q - 1, dtype=np.uint64), pool[rng.integers(0, pool.size, size=n)], pool[rng.integers(0, pool.size, size=n)]])
+        ev = t.forward(x)
+        assert np.array_equal(ev, np.stack([oracle.cyclic_forward(r, Q, t.omega) for r in x]))
+        assert np.array_equal(t.inverse(ev), x)
+        t.close()
+
+
+@pytest.mark.parametrize("q,n", [(Q44, 8), (Q44, 256), (Q44, 8192), (Q60, 2), (Q60, 1024), (Q60, 131072), (12289, 4096), (Q, 64)])
+def test_other_fields_and_explicit_roots(pkg, oracle, lib, q, n):
+    """ntt_forward(coeffs, modulus, omega) takes any NTT-friendly field: both ordinary arithmetic flavours, caller's omega."""
+    w = root_of_order(q, n)
+    for mode in (0, 1):
+        lib.lsr_set_arith_mode(mode)
+        try:
+            t = pkg.CyclicNtt(n, modulus=q, omega=w)
+        finally:
+            lib.lsr_set_arith_mode(0)
+        assert t.omega == w and lib.lsr_ntt_context_is_cyclic(t.handle) == 1
+        x = np.random.default_rng(n + mode).integers(0, q, size=(2, n), dtype=np.uint64)
+        ev = t.forward(x)
+        assert np.array_equal(ev, np.stack([oracle.cyclic_forward(r, q, w) for r in x]))
+        assert np.array_equal(t.inverse(ev), x)
+        t.close()
+
+
+def test_native_order_and_device_api(pkg, oracle, lib):
+    """A cyclic context driven through the ntt.h/batch.h entry points runs the network in its native order:
+    forward output is bit-reversed; lsr_bit_reverse_device restores natural order on the device."""
+    import torch
+    n, batch = 16384, 4
+    t = pkg.CyclicNtt(n)
+    x = np.random.default_rng(3).integers(0, Q, size=(batch, n), dtype=np.uint64)
+    dev = torch.from_numpy(x.view(np.int64)).cuda()
+    out = torch.empty_like(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.lsr_ntt_forward_batch_device(t.handle, dev.data_ptr(), batch, s) == 0
+    assert lib.lsr_bit_reverse_device(out.data_ptr(), dev.data_ptr(), 14, batch, s) == 0
+    torch.cuda.synchronize()
+    want = np.stack([oracle.cyclic_forward(r, Q, t.omega) for r in x])
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+    rev = np.array([int(format(i, "014b")[::-1], 2) for i in range(n)])
+    assert np.array_equal(dev.cpu().numpy().view(np.uint64), want[:, rev])
+    # pointwise product in the field, then back: cyclic convolution theorem
+    y = np.random.default_rng(4).integers(0, Q, size=(batch, n), dtype=np.uint64)
+    dy = torch.from_numpy(y.view(np.int64)).cuda()
+    assert lib.lsr_ntt_forward_batch_device(t.handle, dy.data_ptr(), batch, s) == 0
+    assert lib.lsr_ntt_mul_pointwise_device(t.handle, dy.data_ptr(), dy.data_ptr(), dev.data_ptr(), batch * n, s) == 0
+    assert lib.lsr_ntt_inverse_batch_device(t.handle, dy.data_ptr(), batch, s) == 0
+    torch.cuda.synchronize()
+    got = dy.cpu().numpy().view(np.uint64)
+    fx, fy = want, np.stack([oracle.cyclic_forward(r, Q, t.omega) for r in y])
+    prod = np.array([[int(a) * int(b) % Q for a, b in zip(r1, r2)] for r1, r2 in zip(fx[:1], fy[:1])], dtype=np.uint64)
+    assert np.array_equal(got[0], oracle.cyclic_inverse(prod[0], Q, t.omega))
+    assert lib.lsr_bit_reverse_device(dev.data_ptr(), dev.data_ptr(), 14, batch, s) == -1     # in place is refused
+    assert lib.lsr_cyclic_ntt_forward_batch(pkg.NttContext(12289, 256).handle, x.ctypes.data, 1) == -1   # negacyclic context
+    t.close()
+
+
+# ---- quotient polynomial ------------------------------------------------------------------------------------------
+def instances(rng, m, batch, spoil=()):
+    a = rng.integers(0, Q, size=(batch, m), dtype=np.uint64)
+    b = rng.integers(0, Q, size=(batch, m), dtype=np.uint64)
+    c = np.array([[int(x) * int(y) % Q for x, y in zip(ra, rb)] for ra, rb in zip(a, b)], dtype=np.uint64)
+    for i in spoil:
+        j = int(rng.integers(0, m))
+        c[i, j] = (int(c[i, j]) + 1 + int(rng.integers(0, 1000))) % Q
+    return a, b, c
+
+
+@pytest.mark.parametrize("m", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048])
+def test_quotient_matches_oracle(pkg, oracle, m):
+    batch = 7 if m <= 256 else 3
+    rng = np.random.default_rng(900 + m)
+    a, b, c = instances(rng, m, batch, spoil=(1,))
+    if batch > 4:
+        a[4] = 0; c[4] = 0                        # numerator identically zero -> [0]
+        a[5] = 3; b[5] = 5; c[5] = 15             # constants: degree below m -> [0]
+    plan = pkg.QuotientPlan(m)
+    quot, lens = plan.quotient_batch(a, b, c)
+    for i in range(batch):
+        want, want_len = oracle.quotient(a[i], b[i], c[i])
+        assert lens[i] == want_len, (m, i)
+        if want_len:
+            assert np.array_equal(quot[i], want), (m, i)
+    assert lens[1] == 0
+    if batch > 4:
+        assert lens[4] == 1 and lens[5] == 1 and not quot[4].any() and not quot[5].any()
+    # the reference's return convention
+    assert np.array_equal(plan.compute_quotient_poly(a[0], b[0], c[0]), oracle.quotient(a[0], b[0], c[0])[0][:lens[0]])
+    with pytest.raises(pkg.CoreError):
+        plan.compute_quotient_poly(a[1], b[1], c[1])
+    plan.close()
+
+
+def test_quotient_multiplication_gates_like_r1cs_rs(pkg, oracle):
+    """r1cs.rs:1685-1721 with the NTT modulus: witness (1,7,13,91) -> a=7, b=13, c=91; two gates 2*3=6, 6*4=24."""
+    plan = pkg.QuotientPlan(1)
+    q1 = plan.compute_quotient_poly([7], [13], [91])
+    assert len(q1) <= 1 and all(int(v) < Q for v in q1)
+    plan2 = pkg.QuotientPlan(2)
+    q2 = plan2.compute_quotient_poly([2, 6], [3, 4], [6, 24])
+    assert 1 <= len(q2) <= 2 and all(int(v) < Q for v in q2)
+    assert np.array_equal(q2, oracle.quotient([2, 6], [3, 4], [6, 24])[0][:len(q2)])
+    with pytest.raises(pkg.CoreError):
+        plan2.compute_quotient_poly([2, 6], [3, 4], [6, 25])       # r1cs.rs:1316-1326
+    plan.close(); plan2.close()
+
+
+@pytest.mark.parametrize("m", [4096, 8192, 65536, 131072])
+def test_quotient_identity_at_large_m(pkg, oracle, m):
+    """Sizes beyond the O(m^2) oracle: the identity the reference tests (r1cs.rs:1723-1777),
+    Q(alpha) (alpha^m - 1) = A(alpha) B(alpha) - C(alpha), at random alpha, with A, B, C interpolated by the oracle."""
+    rng = np.random.default_rng(m)
+    a, b, c = instances(rng, m, 3, spoil=(2,))
+    plan = pkg.QuotientPlan(m)
+    quot, lens = plan.quotient_batch(a, b, c)
+    assert lens[2] == 0 and 1 <= lens[0] <= m and 1 <= lens[1] <= m
+    w = oracle.prover_omega(m)
+    for i in (0, 1):
+        pa, pb, pc = (oracle.cyclic_inverse(v[i], Q, w) for v in (a, b, c))
+        for alpha in [12345, int(rng.integers(0, Q, dtype=np.uint64))]:
+            lhs = oracle.eval_poly(quot[i, :lens[i]], alpha, Q) * ((pow(alpha, m, Q) - 1) % Q) % Q
+            rhs = (oracle.eval_poly(pa, alpha, Q) * oracle.eval_poly(pb, alpha, Q) - oracle.eval_poly(pc, alpha, Q)) % Q
+            assert lhs == rhs
+        assert not quot[i, lens[i]:].any()
+    plan.close()
+
+
+def test_quotient_device_api_and_chunking(pkg, oracle, monkeypatch):
+    import torch
+    m, batch = 64, 3000
+    monkeypatch.setenv("LAMBDA_SNARK_QUOTIENT_CHUNK_LOG2", "16")      # 1024 instances per pass -> 3 passes
+    rng = np.random.default_rng(77)
+    a, b, c = instances(rng, m, batch, spoil=(5, 2999))
+    plan = pkg.QuotientPlan(m, device=0)
+    da, db, dc = (torch.from_numpy(v.view(np.int64)).cuda() for v in (a, b, c))
+    dq = torch.empty_like(da)
+    dl = torch.full((batch,), -1, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        plan.quotient_device(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, dq.data_ptr(), dl.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    quot, lens = dq.cpu().numpy().view(np.uint64), dl.cpu().numpy().view(np.uint32)
+    hq, hl = plan.quotient_batch(a, b, c)
+    assert np.array_equal(lens, hl) and lens[5] == 0 and lens[2999] == 0 and (np.delete(lens, [5, 2999]) >= 1).all()
+    ok = lens > 0
+    assert np.array_equal(quot[ok], hq[ok])
+    for i in [0, 1, 6, 1500, 2998]:
+        want, ln = oracle.quotient(a[i], b[i], c[i])
+        assert lens[i] == ln and np.array_equal(quot[i], want)
+    plan.close()
