@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--commits", type=int, default=1024, help="witness vectors per GPU (config 3: 1024)")
     ap.add_argument("--rank", type=int, default=4, help="module rank k of the commitment workload")
     ap.add_argument("--no-commit", action="store_true", help="skip the config-3 section")
+    ap.add_argument("--no-quotient", action="store_true", help="skip the quotient-polynomial section (SURVEY.md §8(f) rank 2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-polys", type=int, default=8192, help="CPU baseline sample: polynomials transformed fwd+inv on one core (~10 s)")
     return ap.parse_args()
@@ -158,6 +159,8 @@ def main():
              "verified_roundtrip": verified, "arith": "f64-FMA Barrett" if ctx.uses_f64 else "u64 Shoup"}
 
     # ---- config 3: rank-k Module-LWE matrix–vector commitment u = INTT(A^T NTT(r)) + e1 ----
+    if args.no_commit:
+        del polys
     if not args.no_commit:
         del polys
         torch.cuda.empty_cache()
@@ -191,6 +194,31 @@ def main():
         extra.update({"commits_per_s": commits_per_s, "commit_rank": k, "commits_per_gpu": args.commits,
                       "commit_roofline_frac": commits_per_s / world * commit_bytes / (HBM_PEAK_GBS * 1e9)})
         lctx.close()
+
+    # ---- "next" row: NTT-path quotient polynomials, 4096 instances of m = 4096 constraints ----
+    if not args.no_quotient:
+        torch.cuda.empty_cache()
+        qm, qb = 4096, 4096
+        plan = pkg.QuotientPlan(qm, device=local)
+        field = pkg.CyclicNtt(qm, device=local)
+        ea = torch.randint(-2**63, 2**63 - 1, (qb, qm), dtype=torch.int64, device="cuda", generator=gen)
+        eb = torch.randint(-2**63, 2**63 - 1, (qb, qm), dtype=torch.int64, device="cuda", generator=gen)
+        ec = torch.empty_like(ea)
+        lib = pkg._abi.lib()
+        assert lib.lsr_ntt_mul_pointwise_device(field.handle, ec.data_ptr(), ea.data_ptr(), eb.data_ptr(), qb * qm, stream) == 0   # satisfied: c = a*b
+        quot = torch.empty_like(ea)
+        qlen = torch.empty(qb, dtype=torch.int32, device="cuda")
+
+        def quotient_step():
+            plan.quotient_device(ea.data_ptr(), eb.data_ptr(), ec.data_ptr(), qb, quot.data_ptr(), qlen.data_ptr(), stream)
+
+        quotient_step()
+        t_q = event_time(quotient_step, reps)
+        extra.update({"quotients_per_s": qb / t_q, "quotient_constraints_per_s": qb * qm / t_q, "quotient_m": qm,
+                      "quotient_all_valid": bool((qlen > 0).all().item()),
+                      # algorithmic bytes: read a, b, c evaluations, write the quotient (4 m words per instance)
+                      "quotient_roofline_frac": qb * qm * 32 / t_q / (HBM_PEAK_GBS * 1e9)})
+        plan.close(); field.close()
 
     if rank == 0:
         transforms = 2 * args.polys * args.steps * world

@@ -15,6 +15,7 @@
 #include "lambda_snark/batch.h"
 #include "lambda_snark/commitment.h"
 #include "lambda_snark/ntt.h"
+#include "lambda_snark/prover.h"
 #include "lambda_snark/types.h"
 #include "lambda_snark/utils.h"
 
@@ -42,6 +43,8 @@ static void test_without_device(void) {
     CHECK(sizeof(LweCommitment) == 16 && sizeof(LweOpening) == 16);
     CHECK(PROFILE_SCALAR_A == 0 && PROFILE_RING_B == 1 && LAMBDA_SNARK_ERR_CRYPTO_FAILED == 4);
     CHECK(lsr_plain_modulus(4096) == 1032193);
+    CHECK(lsr_quotient_plan_create(3, -1) == NULL && lsr_cyclic_ntt_context_create(12289, 8, 5, -1) == NULL);
+    CHECK(lsr_quotient_batch(NULL, NULL, NULL, NULL, 1, NULL, NULL) == -1);
 }
 
 /* cpp-core/tests/test_ntt.cpp */
@@ -153,6 +156,37 @@ static void test_sampler(void) {
     CHECK(labs(positives - negatives) < kSamples / 5);
 }
 
+/* rust-api/lambda-snark/src/ntt.rs tests + r1cs.rs:1706-1721, from plain C */
+static void test_prover_path(void) {
+    const uint64_t q = lsr_prover_modulus();
+    CHECK(q == 18446744069414584321ULL && lsr_prover_root_of_unity(2) == q - 1);
+    NttContext* t2 = lsr_cyclic_ntt_context_create(q, 2, 0, -1);
+    NttContext* t8 = lsr_cyclic_ntt_context_create(q, 8, 0, -1);
+    CHECK(t2 != NULL && t8 != NULL);
+    if (t2 && t8) {
+        uint64_t v2[2] = {1, 2}, v8[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+        CHECK(lsr_cyclic_ntt_forward_batch(t2, v2, 1) == 0 && v2[0] == 3 && v2[1] == q - 1);     /* ntt.rs:293-296 */
+        CHECK(lsr_cyclic_ntt_inverse_batch(t2, v2, 1) == 0 && v2[0] == 1 && v2[1] == 2);
+        CHECK(lsr_cyclic_ntt_forward_batch(t8, v8, 1) == 0 && v8[0] == 36);                      /* ntt.rs:327 */
+        CHECK(lsr_cyclic_ntt_inverse_batch(t8, v8, 1) == 0 && v8[0] == 1 && v8[7] == 8);
+    }
+    ntt_context_free(t2);
+    ntt_context_free(t8);
+    LsrQuotientPlan* plan = lsr_quotient_plan_create(2, -1);
+    CHECK(plan != NULL && lsr_quotient_plan_size(plan) == 2);
+    if (plan) {
+        /* two gates 2*3 = 6, 6*4 = 24 (r1cs.rs:1090-1113), then a wrong product */
+        uint64_t a[4] = {2, 6, 2, 6}, b[4] = {3, 4, 3, 4}, c[4] = {6, 24, 6, 25}, quot[4];
+        uint32_t len[2] = {99, 99};
+        CHECK(lsr_quotient_batch(plan, a, b, c, 2, quot, len) == 0);
+        CHECK(len[0] >= 1 && len[0] <= 2 && len[1] == 0);
+        /* interpolants on the domain {1, -1}: A = 4 - 2X, B = (7 - X)/2, C = 15 - 9X  =>  A B - C = X^2 - 1  =>  Q = 1 */
+        CHECK(len[0] == 1 && quot[0] == 1);
+    }
+    lsr_quotient_plan_free(plan);
+    lsr_quotient_plan_free(NULL);
+}
+
 int main(int argc, char** argv) {
     const int no_gpu = argc > 1 && strcmp(argv[1], "--no-gpu") == 0;
     test_without_device();
@@ -162,6 +196,7 @@ int main(int argc, char** argv) {
         test_ntt();
         test_commitment();
         test_sampler();
+        test_prover_path();
     }
     printf("%s: %d checks, %d failures (%s)\n", failures ? "FAILED" : "ok", checks, failures, lsr_version());
     return failures ? 1 : 0;

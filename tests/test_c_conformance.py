@@ -21,7 +21,7 @@ def build(tmp_path, compiler="gcc", std="-std=c11"):
 def test_headers_compile_as_c_and_cpp(tmp_path, pkg):
     for compiler, std in [("gcc", "-std=c11"), ("g++", "-std=c++17")]:
         probe = tmp_path / ("probe.c" if compiler == "gcc" else "probe.cpp")
-        probe.write_text('#include "lambda_snark/batch.h"\n#include "lambda_snark/utils.h"\n#include "lambda_snark/r1cs.h"\nint main(void) { return sizeof(PublicParams) == 32 ? 0 : 1; }\n')
+        probe.write_text('#include "lambda_snark/batch.h"\n#include "lambda_snark/utils.h"\n#include "lambda_snark/r1cs.h"\n#include "lambda_snark/prover.h"\nint main(void) { return sizeof(PublicParams) == 32 ? 0 : 1; }\n')
         subprocess.run([compiler, std, "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(probe)], check=True)
 
 

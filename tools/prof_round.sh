@@ -11,6 +11,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 tools/ntt_bench.py > $out/pmc_$c.log 2>&1
   J=256 timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $out/pmc_commit_$c -- python3 tools/commit_bench.py > $out/pmc_commit_$c.log 2>&1
 done
+for mm in 4096 65536; do
+  M=$mm B=$((16777216/mm)) timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/quot_$mm -- python3 tools/quotient_bench.py > $out/quotient_m$mm.log 2>&1
+  cp $(ls $out/quot_$mm/*/*kernel_stats.csv | head -1) $out/quotient_m${mm}_kernel_stats.csv
+done
+for mm in 2 64 1024 4096 16384 65536 131072; do M=$mm B=$((16777216/mm)) timeout -k 10 120 python3 tools/quotient_bench.py >> $out/quotient_sweep.txt 2>&1; done
 python3 - $out <<'PY'
 import csv, glob, sys, collections, json
 out = sys.argv[1]
