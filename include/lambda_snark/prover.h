@@ -11,6 +11,7 @@
 #pragma once
 
 #include "lambda_snark/ntt.h"
+#include "lambda_snark/r1cs.h"
 #include "lambda_snark/types.h"
 
 #ifdef __cplusplus
@@ -50,10 +51,30 @@ uint32_t lsr_quotient_plan_size(const LsrQuotientPlan* plan) LSR_NOEXCEPT;
  * the m quotient words of such an instance are unspecified.  Host buffers.  0 / -1. */
 int lsr_quotient_batch(LsrQuotientPlan* plan, const uint64_t* a_evals, const uint64_t* b_evals, const uint64_t* c_evals,
                        size_t batch, uint64_t* quotient, uint32_t* quotient_len) LSR_NOEXCEPT;
-/* same on device-resident buffers, asynchronous on `stream`; d_quotient [batch][m], d_quotient_len [batch] */
+/* same on device-resident buffers, asynchronous on `stream`; d_quotient [batch][m], d_quotient_len [batch].  A plan owns one
+ * workspace: calls on the same plan must be ordered (one stream, or events between streams); the first call of a given
+ * batch size allocates, so make it outside a stream capture. */
 int lsr_quotient_batch_device(LsrQuotientPlan* plan, const uint64_t* d_a_evals, const uint64_t* d_b_evals,
                               const uint64_t* d_c_evals, size_t batch, uint64_t* d_quotient, uint32_t* d_quotient_len,
                               void* stream) LSR_NOEXCEPT;
+
+/* ---- compute_quotient_poly(witness) in full, for one R1CS and many witnesses (r1cs.rs:474-506) ----
+ * The three sparse products of compute_constraint_evals (r1cs.rs:296-304, SparseMatrix::mul_vec sparse_matrix.rs:259-289:
+ * values and witness words reduced mod q as unsigned integers) run on the device in front of the pipeline above.
+ * A, B, C: m x n_vars in the FFI's coordinate form (r1cs.h; duplicate (row, col) entries add up), m = 2^k in [1, 131072],
+ * modulus NTT_MODULUS.  The matrices are copied; NULL on bad shapes / indices or without a GPU. */
+typedef struct LsrR1csProver LsrR1csProver;
+LsrR1csProver* lsr_r1cs_prover_create(const SparseMatrix* A, const SparseMatrix* B, const SparseMatrix* C, int device) LSR_NOEXCEPT;
+void     lsr_r1cs_prover_free(LsrR1csProver* prover) LSR_NOEXCEPT;
+uint32_t lsr_r1cs_prover_num_constraints(const LsrR1csProver* prover) LSR_NOEXCEPT;
+uint32_t lsr_r1cs_prover_num_variables(const LsrR1csProver* prover) LSR_NOEXCEPT;
+/* witnesses = [batch][n_vars] (host).  a/b/c_evals = [batch][m] receive A z, B z, C z (compute_constraint_evals). 0 / -1. */
+int lsr_r1cs_constraint_evals_batch(LsrR1csProver* prover, const uint64_t* witnesses, size_t batch, uint64_t* a_evals,
+                                    uint64_t* b_evals, uint64_t* c_evals) LSR_NOEXCEPT;
+/* quotient / quotient_len as in lsr_quotient_batch; quotient_len[i] = 0 <=> witness i does not satisfy the R1CS
+ * (is_satisfied, r1cs.rs:148-172 — the reference's Err "Witness does not satisfy R1CS constraints"). 0 / -1. */
+int lsr_r1cs_quotient_batch(LsrR1csProver* prover, const uint64_t* witnesses, size_t batch, uint64_t* quotient,
+                            uint32_t* quotient_len) LSR_NOEXCEPT;
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ from ._abi import PROFILE_RING_B, PROFILE_SCALAR_A, LweCommitment, LweOpening, P
 __all__ = [
     "NttContext", "LweContext", "Commitment", "Params", "CoreError", "verify_opening_with_context",
     "sample_gaussian", "verify_openings_batch", "PublicParams", "PROFILE_RING_B", "PROFILE_SCALAR_A",
-    "CyclicNtt", "QuotientPlan", "compute_root_of_unity", "NTT_MODULUS", "NTT_PRIMITIVE_ROOT",
+    "CyclicNtt", "QuotientPlan", "R1csProver", "compute_root_of_unity", "NTT_MODULUS", "NTT_PRIMITIVE_ROOT",
 ]
 
 
@@ -392,3 +392,62 @@ class QuotientPlan:
             self.close()
         except Exception:
             pass
+
+
+class R1csProver:
+    """``R1CS`` restricted to what the prover's hot loop needs (rust-api/lambda-snark/src/r1cs.rs:88-137, 296-304, 474-506):
+    the three matrices on the device, ``compute_constraint_evals`` and ``compute_quotient_poly`` for batches of witnesses.
+    ``a``, ``b``, ``c`` are lists of ``(row, col, value)`` entries of m x n matrices; modulus is NTT_MODULUS, m = 2^k."""
+
+    def __init__(self, m, n, a, b, c, device=-1):
+        self._lib = _abi.lib()
+        self.m, self.n = int(m), int(n)
+        keep, mats = [], []
+        for entries in (a, b, c):
+            arr = (_abi.SparseEntry * max(1, len(entries)))()
+            for i, (row, col, value) in enumerate(entries):
+                arr[i] = _abi.SparseEntry(int(row), int(col), int(value))
+            keep.append(arr)
+            mats.append(_abi.SparseMatrix(ctypes.cast(arr, ctypes.POINTER(_abi.SparseEntry)), len(entries), self.m, self.n))
+        self._h = self._lib.lsr_r1cs_prover_create(ctypes.byref(mats[0]), ctypes.byref(mats[1]), ctypes.byref(mats[2]), device)
+        if not self._h:
+            raise CoreError(f"lsr_r1cs_prover_create(m={m}, n={n}) returned NULL: {_abi.last_error()}")
+
+    def _witnesses(self, witnesses):
+        w = _u64_array(witnesses)
+        if w.size % self.n:
+            raise ValueError("Witness length must equal n")      # r1cs.rs:297
+        return w, w.size // self.n
+
+    def compute_constraint_evals(self, witnesses):
+        w, batch = self._witnesses(witnesses)
+        out = [np.zeros((batch, self.m), dtype=np.uint64) for _ in range(3)]
+        if batch and self._lib.lsr_r1cs_constraint_evals_batch(self._h, w.ctypes.data, batch, *(o.ctypes.data for o in out)) != 0:
+            raise CoreError("lsr_r1cs_constraint_evals_batch failed: " + _abi.last_error())
+        return tuple(out)
+
+    def quotient_batch(self, witnesses):
+        w, batch = self._witnesses(witnesses)
+        quot = np.zeros((batch, self.m), dtype=np.uint64)
+        lens = np.zeros(batch, dtype=np.uint32)
+        if batch and self._lib.lsr_r1cs_quotient_batch(self._h, w.ctypes.data, batch, quot.ctypes.data, lens.ctypes.data) != 0:
+            raise CoreError("lsr_r1cs_quotient_batch failed: " + _abi.last_error())
+        return quot, lens
+
+    def compute_quotient_poly(self, witness):
+        quot, lens = self.quotient_batch(witness)
+        if lens[0] == 0:
+            raise CoreError("Witness does not satisfy R1CS constraints")          # r1cs.rs:477-480
+        return quot[0, :lens[0]].copy()
+
+    def close(self):
+        if self._h:
+            self._lib.lsr_r1cs_prover_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

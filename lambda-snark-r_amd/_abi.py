@@ -128,6 +128,12 @@ SIGNATURES = {
     "lsr_quotient_plan_size": (u32, [vp]),
     "lsr_quotient_batch": (c_int, [vp, vp, vp, vp, c_size, vp, vp]),
     "lsr_quotient_batch_device": (c_int, [vp, vp, vp, vp, c_size, vp, vp, vp]),
+    "lsr_r1cs_prover_create": (vp, [ctypes.POINTER(SparseMatrix), ctypes.POINTER(SparseMatrix), ctypes.POINTER(SparseMatrix), c_int]),
+    "lsr_r1cs_prover_free": (None, [vp]),
+    "lsr_r1cs_prover_num_constraints": (u32, [vp]),
+    "lsr_r1cs_prover_num_variables": (u32, [vp]),
+    "lsr_r1cs_constraint_evals_batch": (c_int, [vp, vp, c_size, vp, vp, vp]),
+    "lsr_r1cs_quotient_batch": (c_int, [vp, vp, c_size, vp, vp]),
 }
 
 

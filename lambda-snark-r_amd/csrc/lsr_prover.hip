@@ -33,7 +33,8 @@ __device__ __forceinline__ uint64_t gold_canon(uint64_t x) { return x >= kGoldil
 
 // copy the constraint evaluations into the workspace (the transforms work in place) and test a_k b_k = c_k on the way
 __global__ void __launch_bounds__(kBlock) load_check_kernel(uint64_t* __restrict__ work, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
-                                                            const uint64_t* __restrict__ c, uint32_t* __restrict__ bad, int logm, size_t per_vector) {
+                                                            const uint64_t* __restrict__ c, uint32_t* __restrict__ bad, int logm, size_t per_vector,
+                                                            bool copy) {
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t base = (size_t)blockIdx.x * kBlock; base < per_vector; base += stride) {   // wave-uniform trip count
         const size_t i = base + threadIdx.x;
@@ -41,9 +42,11 @@ __global__ void __launch_bounds__(kBlock) load_check_kernel(uint64_t* __restrict
         bool wrong = false;
         if (live) {
             const uint64_t x = gold_canon(a[i]), y = gold_canon(b[i]), z = gold_canon(c[i]);
-            work[i] = x;
-            work[per_vector + i] = y;
-            work[2 * per_vector + i] = z;
+            if (copy) {   // (false: a, b, c are the workspace planes themselves, already canonical)
+                work[i] = x;
+                work[per_vector + i] = y;
+                work[2 * per_vector + i] = z;
+            }
             wrong = gold_mul(x, y) != z;
         }
         if (logm >= 6) {   // a wavefront's 64 consecutive constraints belong to one instance
@@ -59,6 +62,26 @@ __global__ void __launch_bounds__(kBlock) numerator_kernel(uint64_t* __restrict_
                                                            size_t count) {
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) a[i] = gold_sub(gold_mul(a[i], b[i]), c[i]);
+}
+
+// compute_constraint_evals (r1cs.rs:296-304): out[mat][inst][row] = sum_e val[e] * z[inst][col[e]] over the row's CSR run.
+// One lane per (instance, row); blockIdx.y selects the matrix.  Witness words are reduced on the way in.
+struct CsrView {
+    const uint32_t* row_ptr;   // [m + 1]
+    const uint32_t* col;
+    const uint64_t* val;       // canonical
+};
+__global__ void __launch_bounds__(kBlock) constraint_evals_kernel(uint64_t* __restrict__ out, CsrView a, CsrView b, CsrView c,
+                                                                  const uint64_t* __restrict__ z, uint32_t n_vars, int logm, size_t per_vector) {
+    const CsrView mat = blockIdx.y == 0 ? a : (blockIdx.y == 1 ? b : c);
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < per_vector; i += stride) {
+        const uint32_t row = (uint32_t)i & ((1u << logm) - 1u);
+        const uint64_t* zi = z + (i >> logm) * n_vars;
+        uint64_t acc = 0;
+        for (uint32_t e = mat.row_ptr[row]; e < mat.row_ptr[row + 1]; ++e) acc = gold_add(acc, gold_mul(mat.val[e], gold_canon(zi[mat.col[e]])));
+        out[blockIdx.y * per_vector + i] = acc;
+    }
 }
 
 constexpr int kSplitTile = 4096;                 // quotient words per workgroup
@@ -193,7 +216,8 @@ static void quotient_pass(LsrQuotientPlan& p, const uint64_t* d_a, const uint64_
     uint32_t* top = p.flags.ptr;
     uint32_t* bad = p.flags.ptr + count;
     LSR_HIP(hipMemsetAsync(p.flags.ptr, 0, 2 * count * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(load_check_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, d_a, d_b, d_c, bad, p.logm, per_vector);
+    hipLaunchKernelGGL(load_check_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, d_a, d_b, d_c, bad, p.logm, per_vector,
+                       d_a != work);
     if (p.ntt) {
         launch_ntt(*p.ntt, work, 3 * count, false, s);                                   // interpolation: r1cs.rs:489-491
         launch_ntt(*p.ntt, work, 3 * count, true, s, nullptr, p.twist.ptr);              // evaluation on the coset psi H
@@ -315,6 +339,119 @@ static LsrQuotientPlan* create_plan(uint32_t m, int device) {
     return p;
 }
 
+}  // namespace lsr
+
+struct LsrR1csProver {
+    uint32_t m = 0, n_vars = 0;
+    LsrQuotientPlan* plan = nullptr;
+    lsr::DeviceBuffer<uint32_t> row_ptr[3], col[3];
+    lsr::DeviceBuffer<uint64_t> val[3];
+    lsr::DeviceBuffer<uint64_t> witness;    // [chunk][n_vars]
+    size_t witness_chunk = 0;
+};
+
+namespace lsr {
+
+static void destroy_prover(LsrR1csProver* r) {
+    if (!r) return;
+    if (r->plan) {
+        try {
+            DeviceGuard guard(r->plan->device);
+            for (int k = 0; k < 3; ++k) { r->row_ptr[k].release(); r->col[k].release(); r->val[k].release(); }
+            r->witness.release();
+        } catch (...) {
+        }
+    }
+    destroy_plan(r->plan);
+    delete r;
+}
+
+static LsrR1csProver* create_prover(const SparseMatrix* const mats[3], int device) {
+    const uint32_t m = mats[0]->n_rows, n_vars = mats[0]->n_cols;
+    for (int k = 0; k < 3; ++k) {
+        if (mats[k]->n_rows != m || mats[k]->n_cols != n_vars || (mats[k]->n_entries && !mats[k]->entries) || mats[k]->n_entries > 0xFFFFFFF0ull) {
+            set_last_error("lsr_r1cs_prover_create: A, B, C must share one shape");
+            return nullptr;
+        }
+        for (size_t e = 0; e < mats[k]->n_entries; ++e)
+            if (mats[k]->entries[e].row >= m || mats[k]->entries[e].col >= n_vars) {
+                set_last_error("lsr_r1cs_prover_create: entry outside the matrix");
+                return nullptr;
+            }
+    }
+    if (n_vars == 0) {
+        set_last_error("lsr_r1cs_prover_create: no variables");
+        return nullptr;
+    }
+    auto* r = new LsrR1csProver;
+    r->m = m;
+    r->n_vars = n_vars;
+    r->plan = create_plan(m, device);
+    if (!r->plan) {
+        delete r;
+        return nullptr;
+    }
+    try {
+        DeviceGuard guard(r->plan->device);
+        for (int k = 0; k < 3; ++k) {   // coordinate form -> CSR (stable counting sort by row)
+            const SparseMatrix& M = *mats[k];
+            std::vector<uint32_t> ptr(m + 1, 0), cols(M.n_entries);
+            std::vector<uint64_t> vals(M.n_entries);
+            for (size_t e = 0; e < M.n_entries; ++e) ++ptr[M.entries[e].row + 1];
+            for (uint32_t i = 0; i < m; ++i) ptr[i + 1] += ptr[i];
+            std::vector<uint32_t> cursor(ptr.begin(), ptr.end() - 1);
+            for (size_t e = 0; e < M.n_entries; ++e) {
+                const uint32_t at = cursor[M.entries[e].row]++;
+                cols[at] = M.entries[e].col;
+                vals[at] = M.entries[e].value % kProverModulus;       // mul_vec: val % modulus
+            }
+            r->row_ptr[k].upload(ptr);
+            if (M.n_entries == 0) { cols.push_back(0); vals.push_back(0); }   // keep the pointers non-null
+            r->col[k].upload(cols);
+            r->val[k].upload(vals);
+        }
+    } catch (const std::exception& e) {
+        set_last_error(std::string("lsr_r1cs_prover_create: ") + e.what());
+        destroy_prover(r);
+        return nullptr;
+    }
+    return r;
+}
+
+// witnesses (host) -> constraint evaluations in the plan's workspace planes, chunk by chunk; then either copy them out
+// (evals != nullptr) or run the quotient pipeline on them in place
+static void prover_run(LsrR1csProver& r, const uint64_t* witnesses, size_t batch, uint64_t* const evals[3], uint64_t* q, uint32_t* len) {
+    LsrQuotientPlan& p = *r.plan;
+    DeviceGuard guard(p.device);
+    std::lock_guard<std::mutex> lock(p.mutex);
+    const size_t chunk = quotient_chunk(p, batch);
+    ensure_workspace(p, chunk, true);
+    if (r.witness_chunk < p.chunk) {
+        r.witness.allocate(p.chunk * r.n_vars);
+        r.witness_chunk = p.chunk;
+    }
+    const CsrView a{r.row_ptr[0].ptr, r.col[0].ptr, r.val[0].ptr}, b{r.row_ptr[1].ptr, r.col[1].ptr, r.val[1].ptr},
+        c{r.row_ptr[2].ptr, r.col[2].ptr, r.val[2].ptr};
+    const size_t slot = p.chunk << p.logm;
+    for (size_t done = 0; done < batch; done += chunk) {
+        const size_t now = std::min(chunk, batch - done);
+        const size_t per_vector = now << p.logm, off = done << p.logm;
+        LSR_HIP(hipMemcpyAsync(r.witness.ptr, witnesses + done * r.n_vars, now * r.n_vars * 8, hipMemcpyHostToDevice, p.stream));
+        hipLaunchKernelGGL(constraint_evals_kernel, dim3(blocks_for(per_vector), 3), dim3(kBlock), 0, p.stream, p.work.ptr, a, b, c, r.witness.ptr,
+                           r.n_vars, p.logm, per_vector);
+        LSR_HIP(hipGetLastError());
+        if (evals) {
+            for (int k = 0; k < 3; ++k)
+                LSR_HIP(hipMemcpyAsync(evals[k] + off, p.work.ptr + k * per_vector, per_vector * 8, hipMemcpyDeviceToHost, p.stream));
+        } else {
+            quotient_pass(p, p.work.ptr, p.work.ptr + per_vector, p.work.ptr + 2 * per_vector, now, p.io.ptr + 3 * slot, p.io_len.ptr, p.stream);
+            LSR_HIP(hipMemcpyAsync(q + off, p.io.ptr + 3 * slot, per_vector * 8, hipMemcpyDeviceToHost, p.stream));
+            LSR_HIP(hipMemcpyAsync(len + done, p.io_len.ptr, now * sizeof(uint32_t), hipMemcpyDeviceToHost, p.stream));
+        }
+        LSR_HIP(hipStreamSynchronize(p.stream));
+    }
+}
+
 // natural-order transforms for host callers: ntt.rs:117-201
 static void cyclic_host(const NttContext& c, uint64_t* values, size_t batch, bool inverse) {
     DeviceGuard guard(c.device);
@@ -408,6 +545,34 @@ int lsr_quotient_batch_device(LsrQuotientPlan* plan, const uint64_t* d_a, const 
     if (batch == 0) return 0;
     return guarded("lsr_quotient_batch_device",
                    [&] { lsr::quotient_device(*plan, d_a, d_b, d_c, batch, d_quotient, d_quotient_len, static_cast<hipStream_t>(stream)); });
+}
+
+LsrR1csProver* lsr_r1cs_prover_create(const SparseMatrix* A, const SparseMatrix* B, const SparseMatrix* C, int device) noexcept {
+    if (!A || !B || !C) return nullptr;
+    try {
+        const SparseMatrix* const mats[3] = {A, B, C};
+        return lsr::create_prover(mats, device);
+    } catch (...) {
+        return nullptr;
+    }
+}
+void lsr_r1cs_prover_free(LsrR1csProver* prover) noexcept { lsr::destroy_prover(prover); }
+uint32_t lsr_r1cs_prover_num_constraints(const LsrR1csProver* prover) noexcept { return prover ? prover->m : 0; }
+uint32_t lsr_r1cs_prover_num_variables(const LsrR1csProver* prover) noexcept { return prover ? prover->n_vars : 0; }
+
+int lsr_r1cs_constraint_evals_batch(LsrR1csProver* prover, const uint64_t* witnesses, size_t batch, uint64_t* a_evals, uint64_t* b_evals,
+                                    uint64_t* c_evals) noexcept {
+    if (!prover || !witnesses || !a_evals || !b_evals || !c_evals) return -1;
+    if (batch == 0) return 0;
+    return guarded("lsr_r1cs_constraint_evals_batch", [&] {
+        uint64_t* const evals[3] = {a_evals, b_evals, c_evals};
+        lsr::prover_run(*prover, witnesses, batch, evals, nullptr, nullptr);
+    });
+}
+int lsr_r1cs_quotient_batch(LsrR1csProver* prover, const uint64_t* witnesses, size_t batch, uint64_t* quotient, uint32_t* quotient_len) noexcept {
+    if (!prover || !witnesses || !quotient || !quotient_len) return -1;
+    if (batch == 0) return 0;
+    return guarded("lsr_r1cs_quotient_batch", [&] { lsr::prover_run(*prover, witnesses, batch, nullptr, quotient, quotient_len); });
 }
 
 }  // extern "C"

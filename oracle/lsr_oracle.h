@@ -106,6 +106,8 @@ int      oracle_cyclic_ntt_forward(uint64_t* data, size_t n, uint64_t q, uint64_
 int      oracle_cyclic_ntt_inverse(uint64_t* data, size_t n, uint64_t q, uint64_t omega);
 void     oracle_cyclic_ntt_naive(const uint64_t* in, uint64_t* out, size_t n, uint64_t q, uint64_t omega);
 uint64_t oracle_eval_poly(const uint64_t* poly, size_t len, uint64_t x, uint64_t q);
+void     oracle_sparse_mul_vec(const uint32_t* rows, const uint32_t* cols, const uint64_t* vals, size_t n_entries, const uint64_t* v,
+                               uint64_t q, uint64_t* out, size_t n_rows);
 size_t   oracle_quotient_ntt_path(const uint64_t* a_evals, const uint64_t* b_evals, const uint64_t* c_evals, size_t m,
                                   uint64_t q, uint64_t root_2_32, uint64_t* quotient);
 

@@ -153,3 +153,12 @@ size_t oracle_quotient_ntt_path(const uint64_t* a_evals, const uint64_t* b_evals
     free(a); free(b); free(c); free(num);
     return result;
 }
+
+/* SparseMatrix::mul_vec (rust-api/lambda-snark/src/sparse_matrix.rs:259-289) on coordinate-form entries:
+ * out[row] = sum (val % q) * (v[col] % q) mod q, unsigned.  compute_constraint_evals (r1cs.rs:296-304) calls it for A, B, C. */
+void oracle_sparse_mul_vec(const uint32_t* rows, const uint32_t* cols, const uint64_t* vals, size_t n_entries, const uint64_t* v, uint64_t q,
+                           uint64_t* out, size_t n_rows) {
+    memset(out, 0, n_rows * 8);
+    for (size_t e = 0; e < n_entries; ++e)
+        out[rows[e]] = addm(out[rows[e]], oracle_mulmod(vals[e] % q, v[cols[e]] % q, q), q);
+}

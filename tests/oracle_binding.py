@@ -54,6 +54,7 @@ class Oracle:
         L.oracle_cyclic_ntt_inverse.restype = ci; L.oracle_cyclic_ntt_inverse.argtypes = [vp, sz, u64, u64]
         L.oracle_cyclic_ntt_naive.argtypes = [vp, vp, sz, u64, u64]
         L.oracle_eval_poly.restype = u64; L.oracle_eval_poly.argtypes = [vp, sz, u64, u64]
+        L.oracle_sparse_mul_vec.argtypes = [vp, vp, vp, sz, vp, u64, vp, sz]
         L.oracle_quotient_ntt_path.restype = sz; L.oracle_quotient_ntt_path.argtypes = [vp, vp, vp, sz, u64, u64, vp]
         self._ntt = {}
         self._lwe = {}
@@ -205,6 +206,15 @@ class Oracle:
     def eval_poly(self, poly, x, q):
         a = np.ascontiguousarray(poly, dtype=np.uint64)
         return self.L.oracle_eval_poly(a.ctypes.data, a.size, x, q)
+
+    def sparse_mul_vec(self, entries, n_rows, v, q):
+        """entries: list of (row, col, value)"""
+        rows = np.array([e[0] for e in entries] or [0], dtype=np.uint32); cols = np.array([e[1] for e in entries] or [0], dtype=np.uint32)
+        vals = np.array([e[2] for e in entries] or [0], dtype=np.uint64)
+        vec = np.ascontiguousarray(v, dtype=np.uint64)
+        out = np.zeros(n_rows, dtype=np.uint64)
+        self.L.oracle_sparse_mul_vec(rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, len(entries), vec.ctypes.data, q, out.ctypes.data, n_rows)
+        return out
 
     def quotient(self, a_evals, b_evals, c_evals):
         """-> (coefficients padded to m words, trimmed length; 0 = remainder non-zero)"""

@@ -237,3 +237,82 @@ def test_quotient_device_api_and_chunking(pkg, oracle, monkeypatch):
         want, ln = oracle.quotient(a[i], b[i], c[i])
         assert lens[i] == ln and np.array_equal(quot[i], want)
     plan.close()
+
+
+# ---- compute_quotient_poly(witness) in full: sparse products + pipeline -------------------------------------------------
+def random_r1cs(rng, m, free_vars, fan_in=3):
+    """m constraints (A_i.z)(B_i.z) = z[free_vars + i] over free_vars + m variables; A_i, B_i touch earlier variables only,
+    so any assignment of the free variables extends to exactly one satisfying witness."""
+    n = free_vars + m
+    a, b, c = [], [], []
+    for i in range(m):
+        for mat in (a, b):
+            for col in rng.choice(free_vars + i, size=min(fan_in, free_vars + i), replace=False):
+                mat.append((i, int(col), int(rng.integers(0, 2**64, dtype=np.uint64))))     # values >= q exercise `val % modulus`
+        c.append((i, free_vars + i, 1))
+    return n, a, b, c
+
+
+def extend_witness(free, m, a, b):
+    z = [int(x) % Q for x in free] + [0] * m
+    rows_a, rows_b = [[] for _ in range(m)], [[] for _ in range(m)]
+    for (i, col, v) in a: rows_a[i].append((col, v % Q))
+    for (i, col, v) in b: rows_b[i].append((col, v % Q))
+    for i in range(m):
+        az = sum(v * z[col] for col, v in rows_a[i]) % Q
+        bz = sum(v * z[col] for col, v in rows_b[i]) % Q
+        z[len(free) + i] = az * bz % Q
+    return np.array(z, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("m,free_vars", [(1, 3), (2, 4), (8, 5), (64, 16), (1024, 40)])
+def test_r1cs_prover_matches_oracle(pkg, oracle, m, free_vars):
+    rng = np.random.default_rng(4000 + m)
+    n, a, b, c = random_r1cs(rng, m, free_vars)
+    a.append(a[0])                                                  # duplicate coordinate entries add up
+    prover = pkg.R1csProver(m, n, a, b, c)
+    batch = 5
+    ws = np.stack([extend_witness(rng.integers(0, Q, size=free_vars, dtype=np.uint64), m, a, b) for _ in range(batch)])
+    ws[3, n - 1] = (int(ws[3, n - 1]) + 1) % Q                      # break the last constraint of witness 3
+    ws[4, 0] = np.uint64(int(ws[4, 0]) + Q if int(ws[4, 0]) + Q < 2**64 else ws[4, 0])   # a non-canonical word: `v[col] % modulus`
+    ea, eb, ec = prover.compute_constraint_evals(ws)
+    for i in range(batch):
+        assert np.array_equal(ea[i], oracle.sparse_mul_vec(a, m, ws[i], Q))      # r1cs.rs:296-304
+        assert np.array_equal(eb[i], oracle.sparse_mul_vec(b, m, ws[i], Q))
+        assert np.array_equal(ec[i], oracle.sparse_mul_vec(c, m, ws[i], Q))
+    quot, lens = prover.quotient_batch(ws)
+    for i in range(batch):
+        want, want_len = oracle.quotient(ea[i], eb[i], ec[i])
+        assert lens[i] == want_len
+        if want_len:
+            assert np.array_equal(quot[i], want)
+    assert lens[3] == 0 and all(lens[i] >= 1 for i in (0, 1, 2, 4))
+    assert np.array_equal(prover.compute_quotient_poly(ws[0]), quot[0, :lens[0]])
+    with pytest.raises(pkg.CoreError):
+        prover.compute_quotient_poly(ws[3])
+    prover.close()
+
+
+def test_r1cs_prover_reference_gates_and_errors(pkg, lib):
+    """create_multiplication_gate / create_two_multiplications of r1cs.rs:1071-1113 over the NTT modulus."""
+    gate = pkg.R1csProver(1, 4, [(0, 1, 1)], [(0, 2, 1)], [(0, 3, 1)])
+    ea, eb, ec = gate.compute_constraint_evals([1, 7, 13, 91])
+    assert (int(ea[0, 0]), int(eb[0, 0]), int(ec[0, 0])) == (7, 13, 91)                        # r1cs.rs:1266-1281
+    assert len(gate.compute_quotient_poly([1, 7, 13, 91])) <= 1
+    with pytest.raises(pkg.CoreError):
+        gate.compute_quotient_poly([1, 7, 13, 90])                                             # r1cs.rs:1316-1326
+    two = pkg.R1csProver(2, 6, [(0, 1, 1), (1, 3, 1)], [(0, 2, 1), (1, 4, 1)], [(0, 3, 1), (1, 5, 1)])
+    q2 = two.compute_quotient_poly([1, 2, 3, 6, 4, 24])
+    assert 1 <= len(q2) <= 2
+    with pytest.raises(pkg.CoreError):
+        two.compute_quotient_poly([1, 2, 3, 7, 4, 24])
+    with pytest.raises(ValueError):
+        two.compute_quotient_poly([1, 2, 3])
+    with pytest.raises(pkg.CoreError):
+        pkg.R1csProver(3, 4, [], [], [])                     # m not a power of two
+    with pytest.raises(pkg.CoreError):
+        pkg.R1csProver(2, 4, [(2, 0, 1)], [], [])            # row outside the matrix
+    empty = pkg.R1csProver(4, 3, [], [], [])                 # all-zero matrices: 0 * 0 = 0 holds, Q = [0]
+    assert list(empty.compute_quotient_poly([5, 6, 7])) == [0]
+    assert lib.lsr_r1cs_prover_num_constraints(empty._h) == 4 and lib.lsr_r1cs_prover_num_variables(empty._h) == 3
+    gate.close(); two.close(); empty.close()

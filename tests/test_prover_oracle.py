@@ -123,6 +123,20 @@ def test_quotient_rejects_unsatisfied_instances(oracle):
     assert ln == 1 and not quot.any()
 
 
+def test_sparse_mul_vec_like_sparse_matrix_rs(oracle):
+    """sparse_matrix.rs:259-289 incl. the `% modulus` of both operands; r1cs.rs:1266-1301 evaluations."""
+    gate = ([(0, 1, 1)], [(0, 2, 1)], [(0, 3, 1)])
+    w = [1, 7, 13, 91]
+    assert [int(oracle.sparse_mul_vec(m, 1, w, Q)[0]) for m in gate] == [7, 13, 91]
+    two_a, two_b, two_c = [(0, 1, 1), (1, 3, 1)], [(0, 2, 1), (1, 4, 1)], [(0, 3, 1), (1, 5, 1)]
+    w = [1, 2, 3, 6, 4, 24]
+    assert list(oracle.sparse_mul_vec(two_a, 2, w, Q)) == [2, 6] and list(oracle.sparse_mul_vec(two_b, 2, w, Q)) == [3, 4]
+    assert list(oracle.sparse_mul_vec(two_c, 2, w, Q)) == [6, 24]
+    big = [(0, 0, 2**64 - 1), (0, 1, Q + 5)]
+    v = [2**64 - 2, 3]
+    assert int(oracle.sparse_mul_vec(big, 1, v, Q)[0]) == (((2**64 - 1) % Q) * ((2**64 - 2) % Q) + 5 * 3) % Q
+
+
 def test_product_host_math_for_the_prover_path(lib):
     assert lib.lsr_prover_modulus() == Q and lib.lsr_prover_root_2_32() == ROOT_2_32
     for k in range(0, 33):
@@ -138,6 +152,11 @@ def test_product_host_math_for_the_prover_path(lib):
     assert lib.lsr_cyclic_ntt_forward_batch(None, None, 1) == -1
     assert lib.lsr_quotient_batch(None, None, None, None, 1, None, None) == -1
     assert lib.lsr_quotient_plan_size(None) == 0
+    assert not lib.lsr_r1cs_prover_create(None, None, None, -1)
+    assert lib.lsr_r1cs_prover_num_constraints(None) == 0 and lib.lsr_r1cs_prover_num_variables(None) == 0
+    assert lib.lsr_r1cs_quotient_batch(None, None, 1, None, None) == -1
+    assert lib.lsr_r1cs_constraint_evals_batch(None, None, 1, None, None, None) == -1
+    lib.lsr_r1cs_prover_free(None)
     lib.lsr_quotient_plan_free(None)
     if lib.lsr_device_count() == 0:
         assert not lib.lsr_quotient_plan_create(8, -1)                         # fails loudly: no CPU fallback
