@@ -132,3 +132,100 @@ def test_device_api_is_graph_capturable(pkg, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(buf.cpu().numpy().view(np.uint64), oracle.ntt_forward(q, n, want))
     ctx.close()
+
+
+# ---- prover path (include/lambda_snark/prover.h) --------------------------------------------------------------------
+GOLD = 18446744069414584321
+
+
+def _gold_instances(rng, m, batch):
+    a = rng.integers(0, GOLD, size=(batch, m), dtype=np.uint64)
+    b = rng.integers(0, GOLD, size=(batch, m), dtype=np.uint64)
+    c = np.array([[int(x) * int(y) % GOLD for x, y in zip(ra, rb)] for ra, rb in zip(a, b)], dtype=np.uint64)
+    return a, b, c
+
+
+def test_quotient_plans_from_threads(pkg, oracle):
+    """Private plans run concurrently; one shared plan is used by one call at a time (its mutex serialises the host API)."""
+    rng = np.random.default_rng(99)
+    m = 256
+    cases = [_gold_instances(rng, m, 6) for _ in range(4)]
+    want = [[oracle.quotient(a[i], b[i], c[i]) for i in range(6)] for a, b, c in cases]
+    shared = pkg.QuotientPlan(m)
+    errors = []
+
+    def worker(idx, plan):
+        try:
+            own = plan or pkg.QuotientPlan(m)
+            for _ in range(5):
+                quot, lens = own.quotient_batch(*cases[idx])
+                for i in range(6):
+                    assert lens[i] == want[idx][i][1] and np.array_equal(quot[i], want[idx][i][0])
+            if plan is None:
+                own.close()
+        except Exception as e:          # noqa: BLE001 — collected and re-raised below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i, None if i % 2 else shared)) for i in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    shared.close()
+    assert not errors, errors
+
+
+def test_quotient_device_api_is_graph_capturable(pkg, oracle):
+    import torch
+    m, batch = 512, 8
+    rng = np.random.default_rng(5)
+    a, b, c = _gold_instances(rng, m, batch)
+    c[3, 7] ^= np.uint64(1)
+    plan = pkg.QuotientPlan(m, device=0)
+    da, db, dc = (torch.from_numpy(v.view(np.int64)).cuda() for v in (a, b, c))
+    dq = torch.zeros_like(da)
+    dl = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):      # warm-up outside capture: the first call allocates the plan's workspace
+        plan.quotient_device(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, dq.data_ptr(), dl.data_ptr(), side.cuda_stream)
+    side.synchronize()
+    dq.zero_(); dl.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        plan.quotient_device(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, dq.data_ptr(), dl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        dq.zero_(); dl.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        quot, lens = dq.cpu().numpy().view(np.uint64), dl.cpu().numpy().view(np.uint32)
+        for i in range(batch):
+            w, ln = oracle.quotient(a[i], b[i], c[i])
+            assert lens[i] == ln and (ln == 0 or np.array_equal(quot[i], w))
+        assert lens[3] == 0
+    plan.close()
+
+
+def test_prover_handles_do_not_leak(pkg):
+    import torch
+    rng = np.random.default_rng(8)
+    a, b, c = _gold_instances(rng, 1024, 4)
+
+    def cycle():
+        plan = pkg.QuotientPlan(1024)
+        plan.quotient_batch(a, b, c)
+        plan.close()
+        t = pkg.CyclicNtt(4096)
+        t.inverse(t.forward(a.reshape(-1)))
+        t.close()
+        prover = pkg.R1csProver(2, 6, [(0, 1, 1), (1, 3, 1)], [(0, 2, 1), (1, 4, 1)], [(0, 3, 1), (1, 5, 1)])
+        prover.quotient_batch([1, 2, 3, 6, 4, 24])
+        prover.close()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(30):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 30 create/use/free cycles"
