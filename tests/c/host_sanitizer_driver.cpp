@@ -24,6 +24,23 @@ int main() {
     CHECK(select_commit_modulus(12289, 4096) == 17592169062401ull && select_commit_modulus(5, 65536) == 17592182243329ull && select_commit_modulus(5, 3) == 0);
     CHECK(plain_modulus_for(4096) == 1032193 && plain_modulus_for(65536) == 786433);
     CHECK(largest_prime_congruent_one(0, 20) == 0 && largest_prime_congruent_one(8192, 1) == 0);
+    // prover path: cyclic tables over the Goldilocks field and a 44-bit field
+    const uint64_t gq = kProverModulus, w8 = prover_root_of_unity(gq, 8);
+    CHECK(w8 != 0 && powmod(w8, 4, gq) == gq - 1 && prover_root_of_unity(gq, 12) == 0 && prover_root_of_unity(12289, 8) == 0);
+    CHECK(prover_root_of_unity(gq, 1ull << 32) == kProverRoot2_32 && prover_root_of_unity(gq, 1ull << 33) == 0);
+    CHECK(cyclic_params_valid(gq, 8, w8, &logn) && logn == 3 && !cyclic_params_valid(gq, 8, 5, &logn) && !cyclic_params_valid(gq, 6, w8, &logn));
+    CHECK(!cyclic_params_valid(gq - 2, 8, w8, &logn) && !cyclic_params_valid(gq, 1u << 18, w8, &logn) && !cyclic_params_valid(gq, 8, gq, &logn));
+    for (uint32_t n : {2u, 8u, 131072u}) {
+        const uint64_t w = prover_root_of_unity(gq, n);
+        int ln = 0;
+        CHECK(cyclic_params_valid(gq, n, w, &ln));
+        const TwiddleTables c = build_cyclic_twiddles(gq, n, ln, w);
+        CHECK(c.fwd.size() == n && c.fwd[0] == 1 && c.fwd[1] == 1 && mulmod(c.n_inv, n, gq) == 1);
+        for (uint32_t i = 0; i < n; i += (n > 64 ? 4099 : 1)) CHECK(mulmod(c.fwd[i], c.inv[i], gq) == 1);
+        if (n >= 8)   // stage-order layout: entry m + i = w^((n/2m) bitrev(i))
+            CHECK(c.fwd[3] == powmod(w, n / 4, gq) && c.fwd[5] == powmod(w, n / 4, gq) && c.fwd[6] == powmod(w, n / 8, gq) &&
+                  c.fwd[7] == powmod(w, 3 * (n / 8), gq));
+    }
     std::vector<uint64_t> words(12293, 0x0123456789abcdefull);
     LweCommitment com{words.data(), words.size()};
     uint64_t inputs[] = {1, 471}, alpha = 0;

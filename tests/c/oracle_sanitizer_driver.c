@@ -56,6 +56,26 @@ int main(void) {
     CHECK(oracle_lwe_commit(c, long_msg, 300, 5, c1) == 0 && oracle_lwe_verify(c, c1, w, long_msg, 256) == 1 && oracle_lwe_verify(c, c1, w, long_msg, 300) == 0);
     free(c1); free(c2); free(c3); free(a); free(b); free(naive);
     oracle_lwe_free(c); oracle_ntt_free(t); oracle_ntt_free(small);
+    {   /* prover path: ntt.rs known answers, a quotient with and without remainder, the sparse product */
+        const uint64_t gq = oracle_prover_modulus(), g = oracle_prover_root_2_32();
+        uint64_t v[8] = {1, 2, 3, 4, 5, 6, 7, 8}, out[8];
+        const uint64_t w8 = oracle_root_of_unity(8, gq, g);
+        oracle_cyclic_ntt_naive(v, out, 8, gq, w8);
+        if (oracle_cyclic_ntt_forward(v, 8, gq, w8) != 0 || v[0] != 36 || memcmp(v, out, sizeof v) != 0) return 1;
+        if (oracle_cyclic_ntt_inverse(v, 8, gq, w8) != 0 || v[0] != 1 || v[7] != 8) return 1;
+        if (oracle_cyclic_ntt_forward(v, 6, gq, w8) != -1 || oracle_root_of_unity(12, gq, g) != 0) return 1;
+        uint64_t a[2] = {2, 6}, b[2] = {3, 4}, c[2] = {6, 24}, quot[2];
+        if (oracle_quotient_ntt_path(a, b, c, 2, gq, g, quot) != 1 || quot[0] != 1) return 1;
+        c[1] = 25;
+        if (oracle_quotient_ntt_path(a, b, c, 2, gq, g, quot) != 0) return 1;
+        uint64_t one = 7, zero = 0;
+        if (oracle_quotient_ntt_path(&one, &one, &one, 1, gq, g, quot) != 0 || oracle_quotient_ntt_path(&zero, &one, &zero, 1, gq, g, quot) != 1) return 1;
+        const uint32_t rows[3] = {0, 1, 0}, cols[3] = {1, 0, 1};
+        const uint64_t vals[3] = {5, ~0ull, 2}, z[2] = {3, 4};
+        oracle_sparse_mul_vec(rows, cols, vals, 3, z, gq, out, 2);
+        if (out[0] != 28 || out[1] != (uint64_t)(((unsigned __int128)(~0ull % gq) * 3) % gq)) return 1;
+        if (oracle_eval_poly(v, 8, 2, gq) != 1 + 4 + 12 + 32 + 80 + 192 + 448 + 1024) return 1;
+    }
     puts("oracle sanitizer driver ok");
     return 0;
 }

@@ -18,7 +18,7 @@ def run(cmd, **kw):
 def test_oracle_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "oracle_san")
     run(["gcc", "-std=c11", *SAN, "-I" + os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests/c/oracle_sanitizer_driver.c"),
-         os.path.join(ROOT, "oracle/lsr_oracle.c"), "-lm", "-o", exe])
+         os.path.join(ROOT, "oracle/lsr_oracle.c"), os.path.join(ROOT, "oracle/lsr_prover_oracle.c"), "-lm", "-o", exe])
     assert "ok" in run([exe], env=ENV)
 
 
