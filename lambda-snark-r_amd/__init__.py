@@ -239,6 +239,12 @@ class Commitment:
     def as_bytes(self):
         return self.as_words().tobytes()
 
+    def serialize(self):
+        """The bincode form of the Rust type (commitment.rs:112-121, pinned by tests/serialization.rs:128-153): a u64
+        element count followed by the words, little endian.  There is no deserialisation (it needs an LweContext)."""
+        words = self.as_words()
+        return int(words.size).to_bytes(8, "little") + words.astype("<u8").tobytes()
+
     def __len__(self):
         return self._p.contents.len
 

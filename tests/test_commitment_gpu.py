@@ -130,6 +130,10 @@ def test_rust_wrapper_flow(pkg, ctx):
     assert not pkg.verify_opening_with_context(rctx, c1, [1, 2, 3, 5])
     twin = c1.clone()
     assert np.array_equal(twin.as_words(), c1.as_words()) and len(twin) == len(c1)
+    # tests/serialization.rs:128-153: bincode = 8-byte element count + the words; data[0] = payload byte length (types.h:30-35)
+    blob = c1.serialize()
+    assert len(blob) == 8 + len(c1) * 8 and int.from_bytes(blob[:8], "little") == len(c1)
+    assert int.from_bytes(blob[8:16], "little") == (len(c1) - 1) * 8 and blob[8:] == c1.as_bytes()
     with pytest.raises(ValueError):
         pkg.Commitment.linear_combine(rctx, [], [])
     # ScalarA profile is sent as ring_degree = 1 and rejected, as by the reference
