@@ -154,9 +154,9 @@ def instances(rng, m, batch, spoil=()):
     return a, b, c
 
 
-@pytest.mark.parametrize("m", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize("m", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
 def test_quotient_matches_oracle(pkg, oracle, m):
-    batch = 7 if m <= 256 else 3
+    batch = 7 if m <= 256 else (3 if m <= 2048 else 2)
     rng = np.random.default_rng(900 + m)
     a, b, c = instances(rng, m, batch, spoil=(1,))
     if batch > 4:
