@@ -24,6 +24,9 @@
  *     holds no forward KAT and cannot be built here: SEAL absent).  They are pinned instead by the
  *     mathematical definition out[i] = a(psi^(2*bitrev(i)+1)) with psi the minimal primitive 2n-th
  *     root (checked by an independent O(n^2) evaluation in tests) and by the survey's check values.
+ *   - sampler: besides test_utils.cpp's moment bounds, the reference's own utils.cpp compiled into oracle/_ref
+ *     (`make ref`) is compared with this restatement in tests/test_reference_sampler.py (distribution against the
+ *     restated table, tail bound, argument contract).
  *   - commitment bytes: unpinnable (reference is non-deterministic, commitment.cpp:142); bit-exactness
  *     is GPU-vs-this-oracle under the same seeds.
  */
