@@ -39,3 +39,20 @@ def sharded_transform(polys, transform, group=None, dst=0):
     lo, hi = shard_bounds(polys.shape[0], world, rank)
     local = transform(polys[lo:hi]) if hi > lo else polys[:0].copy()
     return gather_batches(local, dst=dst, group=group)
+
+
+def sharded_map(inputs, fn, group=None, dst=0):
+    """Several aligned host batches in, several out: every rank holds `inputs` (arrays with one leading batch dimension),
+    runs ``fn(*slices)`` on its contiguous slice (e.g. ``QuotientPlan.quotient_batch`` -> (coefficients, lengths)) and rank
+    `dst` receives the tuple of gathered outputs; other ranks get None."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    batch = inputs[0].shape[0]
+    if any(a.shape[0] != batch for a in inputs):
+        raise ValueError("inputs must share the batch dimension")
+    lo, hi = shard_bounds(batch, world, rank)
+    outs = fn(*(a[lo:hi] for a in inputs))
+    gathered = [gather_batches(np.asarray(o), dst=dst, group=group) for o in outs]
+    return None if rank != dst else tuple(gathered)
+
