@@ -11,6 +11,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "libref_utils.so")
+if not os.path.exists(REF) and os.path.exists("/root/reference/cpp-core/src/utils.cpp"):     # CPU container: build it on demand
+    import subprocess
+    subprocess.run(["make", "ref"], cwd=os.path.join(ROOT, "oracle"), check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not built (needs /root/reference at build time)")
 
