@@ -101,6 +101,6 @@ def test_gpu_sampler_against_the_reference_distribution(ref, pkg):
     a = np.bincount(theirs - lo, minlength=hi - lo + 1).astype(float)
     b = np.bincount(ours - lo, minlength=hi - lo + 1).astype(float)
     keep = (a + b) >= 40
-    stat = float((((a - b) ** 2) / (a + b))[keep].sum())                       # two-sample chi-square, equal sizes
+    stat = float(((a[keep] - b[keep]) ** 2 / (a[keep] + b[keep])).sum())      # two-sample chi-square, equal sizes
     dof = int(keep.sum()) - 1
     assert stat < dof + 6.0 * math.sqrt(2.0 * dof), (stat, dof)
