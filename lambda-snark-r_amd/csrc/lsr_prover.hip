@@ -28,8 +28,12 @@ __device__ __forceinline__ uint64_t gold_canon(uint64_t x) { return x >= kGoldil
 //      forward = P F_{1/omega}           : natural-order values -> m x (inverse DFT), bit-reversed
 //      inverse = (P F_{1/omega})^-1      = m^-1 F_omega P : bit-reversed coefficients -> natural-order evaluations
 // so  e --forward--> m P coeffs --[x psi^bitrev(p) fused into the read-in]--inverse--> evaluations on psi H (natural order)
-// needs no permutation and no scaling, and the way back is forward again: z = m P (psi^j Q_j)_j.  Only the m words of Q are
-// put in natural order (through LDS), multiplied there by -(2m)^-1 psi^-j.
+// needs no permutation and no scaling, and the way back is forward again.
+// C enters linearly, so it never goes to the coset: modulo X^m + 1 (whose roots are psi H) Z_H = -2 and C is its own
+// remainder, hence Q = (C - (A B mod X^m + 1)) / 2 coefficient by coefficient.  Six transforms in all: A, B, C interpolated
+// (c^ = m P c stays where it is), A and B evaluated on the coset and multiplied, one transform back (z = m P (psi^j g_j)_j
+// with g = A B mod X^m + 1), and the finish Q_j = (2m)^-1 (c^[p] - psi^-j z[p]), p = bitrev(j) — the only place where m
+// words are put in natural order (through LDS).
 
 // copy the constraint evaluations into the workspace (the transforms work in place) and test a_k b_k = c_k on the way
 __global__ void __launch_bounds__(kBlock) load_check_kernel(uint64_t* __restrict__ work, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
@@ -57,11 +61,10 @@ __global__ void __launch_bounds__(kBlock) load_check_kernel(uint64_t* __restrict
     }
 }
 
-// evaluations of A B - C on the coset, written over A's
-__global__ void __launch_bounds__(kBlock) numerator_kernel(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, const uint64_t* __restrict__ c,
-                                                           size_t count) {
+// evaluations of A B on the coset, written over A's
+__global__ void __launch_bounds__(kBlock) product_kernel(uint64_t* __restrict__ a, const uint64_t* __restrict__ b, size_t count) {
     const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) a[i] = gold_sub(gold_mul(a[i], b[i]), c[i]);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) a[i] = gold_mul(a[i], b[i]);
 }
 
 // compute_constraint_evals (r1cs.rs:296-304): out[mat][inst][row] = sum_e val[e] * z[inst][col[e]] over the row's CSR run.
@@ -88,11 +91,13 @@ constexpr int kSplitTile = 4096;                 // quotient words per workgroup
 constexpr int kSplitPerThread = kSplitTile / kBlock;
 __device__ __forceinline__ int split_slot(int i) { return i + (i >> 6); }   // one pad word per 64
 
-// z = [instances][m] in bit-reversed order -> quotient[inst][j] = z[inst][bitrev(j)] * scale[j]  (scale[j] = -(2m)^-1 psi^-j),
-// and per instance `top` = 1 + highest non-zero index.  LOGM_HIGH: m >= 4096, one workgroup moves the 4096 words whose
-// index has a fixed middle field (bits 6..logm-7): 64-word runs on both the read and the write side.
+// z, chat = [instances][m] in bit-reversed order -> quotient[inst][j] = half_m_inv * chat[inst][p] - untwist[p] * z[inst][p],
+// p = bitrev(j), untwist[p] = (2m)^-1 psi^-bitrev(p); and per instance `top` = 1 + highest non-zero index.
+// LOGM_HIGH: m >= 4096, one workgroup moves the 4096 words whose index has a fixed middle field (bits 6..logm-7):
+// 64-word runs on both the read and the write side.
 template <bool LOGM_HIGH>
-__global__ void __launch_bounds__(kBlock) finish_quotient_kernel(const uint64_t* __restrict__ z, const uint64_t* __restrict__ scale,
+__global__ void __launch_bounds__(kBlock) finish_quotient_kernel(const uint64_t* __restrict__ z, const uint64_t* __restrict__ chat,
+                                                                 const uint64_t* __restrict__ untwist, uint64_t half_m_inv,
                                                                  uint64_t* __restrict__ quotient, uint32_t* __restrict__ top, int logm, size_t total) {
     __shared__ uint64_t tile[kSplitTile + kSplitTile / 64];
     const int t = threadIdx.x;
@@ -107,7 +112,9 @@ __global__ void __launch_bounds__(kBlock) finish_quotient_kernel(const uint64_t*
 #pragma unroll
         for (int r = 0; r < kSplitPerThread; ++r) {
             const int A = wave * kSplitPerThread + r;
-            tile[A * 65 + lane] = z[(inst << logm) + (((uint32_t)A << (logm - 6)) | (B << 6) | (uint32_t)lane)];
+            const uint32_t pidx = ((uint32_t)A << (logm - 6)) | (B << 6) | (uint32_t)lane;
+            const size_t g = (inst << logm) + pidx;
+            tile[A * 65 + lane] = gold_sub(gold_mul(chat[g], half_m_inv), gold_mul(z[g], untwist[pidx]));
         }
         __syncthreads();
         uint32_t best = 0;
@@ -115,7 +122,7 @@ __global__ void __launch_bounds__(kBlock) finish_quotient_kernel(const uint64_t*
         for (int r = 0; r < kSplitPerThread; ++r) {
             const int Cout = wave * kSplitPerThread + r;              // top field of the natural index
             const uint32_t nat = ((uint32_t)Cout << (logm - 6)) | (Brev << 6) | (uint32_t)lane;
-            const uint64_t h = gold_mul(tile[(__brev((uint32_t)lane) >> 26) * 65 + (__brev((uint32_t)Cout) >> 26)], scale[nat]);
+            const uint64_t h = tile[(__brev((uint32_t)lane) >> 26) * 65 + (__brev((uint32_t)Cout) >> 26)];
             quotient[(inst << logm) + nat] = h;
             if (h != 0) best = nat + 1;                                // nat grows with r within a thread
         }
@@ -131,7 +138,7 @@ __global__ void __launch_bounds__(kBlock) finish_quotient_kernel(const uint64_t*
             if (g < total) {
                 const uint32_t j = (uint32_t)p & mmask;
                 const uint32_t nat = logm ? (__brev(j) >> (32 - logm)) : 0u;
-                tile[split_slot((p & ~(int)mmask) | (int)nat)] = z[g];
+                tile[split_slot((p & ~(int)mmask) | (int)nat)] = gold_sub(gold_mul(chat[g], half_m_inv), gold_mul(z[g], untwist[j]));
             }
         }
         __syncthreads();
@@ -143,7 +150,7 @@ __global__ void __launch_bounds__(kBlock) finish_quotient_kernel(const uint64_t*
             const uint32_t nat = (uint32_t)p & mmask;
             uint64_t h = 0;
             if (live) {
-                h = gold_mul(tile[split_slot(p)], scale[nat]);
+                h = tile[split_slot(p)];
                 quotient[g] = h;
             }
             if (logm >= 6) {   // a wavefront's 64 consecutive words belong to one instance: one atomic per wave
@@ -170,7 +177,8 @@ struct LsrQuotientPlan {
     int device = 0;
     NttContext* ntt = nullptr;                // size m, on the conjugate root omega_m^-1 (absent for m = 1)
     lsr::DeviceBuffer<uint64_t> twist;        // psi^bitrev(p), p < m
-    lsr::DeviceBuffer<uint64_t> untwist;      // -(2m)^-1 psi^-j, j < m
+    lsr::DeviceBuffer<uint64_t> untwist;      // (2m)^-1 psi^-bitrev(p), p < m
+    uint64_t half_m_inv = 0;                  // (2m)^-1
     std::mutex mutex;                         // guards the workspace and `stream`
     lsr::DeviceBuffer<uint64_t> work;         // [3][chunk][m]
     lsr::DeviceBuffer<uint32_t> flags;        // top[chunk], bad[chunk]
@@ -220,16 +228,15 @@ static void quotient_pass(LsrQuotientPlan& p, const uint64_t* d_a, const uint64_
                        d_a != work);
     if (p.ntt) {
         launch_ntt(*p.ntt, work, 3 * count, false, s);                                   // interpolation: r1cs.rs:489-491
-        launch_ntt(*p.ntt, work, 3 * count, true, s, nullptr, p.twist.ptr);              // evaluation on the coset psi H
-        hipLaunchKernelGGL(numerator_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, work + per_vector, work + 2 * per_vector,
-                           per_vector);                                                  // r1cs.rs:495-499, pointwise
+        launch_ntt(*p.ntt, work, 2 * count, true, s, nullptr, p.twist.ptr);              // A, B on the coset psi H
+        hipLaunchKernelGGL(product_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, work + per_vector, per_vector);   // r1cs.rs:495
         launch_ntt(*p.ntt, work, count, false, s);                                       // back to (twisted, bit-reversed) coefficients
         if (p.logm >= 12) {
             hipLaunchKernelGGL(finish_quotient_kernel<true>, dim3(static_cast<unsigned>(per_vector / kSplitTile)), dim3(kBlock), 0, s, work,
-                               p.untwist.ptr, d_q, top, p.logm, per_vector);
+                               work + 2 * per_vector, p.untwist.ptr, p.half_m_inv, d_q, top, p.logm, per_vector);
         } else {
             hipLaunchKernelGGL(finish_quotient_kernel<false>, dim3(static_cast<unsigned>((per_vector + kSplitTile - 1) / kSplitTile)), dim3(kBlock), 0, s,
-                               work, p.untwist.ptr, d_q, top, p.logm, per_vector);
+                               work, work + 2 * per_vector, p.untwist.ptr, p.half_m_inv, d_q, top, p.logm, per_vector);
         }
     } else {
         LSR_HIP(hipMemsetAsync(d_q, 0, per_vector * 8, s));                              // m = 1: constants, Q = 0 when a b = c
@@ -320,10 +327,11 @@ static LsrQuotientPlan* create_plan(uint32_t m, int device) {
         if (m >= 2) {
             const uint64_t psi = prover_root_of_unity(q, 2ull * m), psi_inv = invmod_prime(psi, q);
             std::vector<uint64_t> twist(m), untwist(m);
-            uint64_t up = 1, down = q - invmod_prime((2ull * m) % q, q);   // -(2m)^-1
+            p->half_m_inv = invmod_prime((2ull * m) % q, q);
+            uint64_t up = 1, down = p->half_m_inv;
             for (uint32_t j = 0; j < m; ++j) {
                 twist[bit_reverse(j, p->logm)] = up;
-                untwist[j] = down;
+                untwist[bit_reverse(j, p->logm)] = down;
                 up = mulmod(up, psi, q);
                 down = mulmod(down, psi_inv, q);
             }
