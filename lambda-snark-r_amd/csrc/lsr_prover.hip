@@ -182,7 +182,7 @@ struct LsrQuotientPlan {
     std::mutex mutex;                         // guards the workspace and `stream`
     lsr::DeviceBuffer<uint64_t> work;         // [3][chunk][m]
     lsr::DeviceBuffer<uint32_t> flags;        // top[chunk], bad[chunk]
-    lsr::DeviceBuffer<uint64_t> io;           // host-API staging: evaluations in [3][chunk][m], quotient out [chunk][m]
+    lsr::DeviceBuffer<uint64_t> io;           // host-API staging of the quotient: [chunk][m]
     lsr::DeviceBuffer<uint32_t> io_len;
     size_t chunk = 0;
     hipStream_t stream = nullptr;
@@ -210,8 +210,8 @@ static void ensure_workspace(LsrQuotientPlan& p, size_t chunk, bool host_io) {
         p.io_len.release();
         p.chunk = chunk;
     }
-    if (host_io && p.io.count < 4 * p.chunk * p.m) {
-        p.io.allocate(4 * p.chunk * p.m);
+    if (host_io && p.io.count < p.chunk * p.m) {
+        p.io.allocate(p.chunk * p.m);
         p.io_len.allocate(p.chunk);
     }
 }
@@ -263,15 +263,15 @@ static void quotient_host(LsrQuotientPlan& p, const uint64_t* a, const uint64_t*
     std::lock_guard<std::mutex> lock(p.mutex);
     const size_t chunk = quotient_chunk(p, batch);
     ensure_workspace(p, chunk, true);
-    const size_t slot = p.chunk << p.logm;
     for (size_t done = 0; done < batch; done += chunk) {
         const size_t now = std::min(chunk, batch - done);
-        const size_t off = done << p.logm, bytes = (now << p.logm) * 8;
-        LSR_HIP(hipMemcpyAsync(p.io.ptr, a + off, bytes, hipMemcpyHostToDevice, p.stream));
-        LSR_HIP(hipMemcpyAsync(p.io.ptr + slot, b + off, bytes, hipMemcpyHostToDevice, p.stream));
-        LSR_HIP(hipMemcpyAsync(p.io.ptr + 2 * slot, c + off, bytes, hipMemcpyHostToDevice, p.stream));
-        quotient_pass(p, p.io.ptr, p.io.ptr + slot, p.io.ptr + 2 * slot, now, p.io.ptr + 3 * slot, p.io_len.ptr, p.stream);
-        LSR_HIP(hipMemcpyAsync(q + off, p.io.ptr + 3 * slot, bytes, hipMemcpyDeviceToHost, p.stream));
+        const size_t off = done << p.logm, words = now << p.logm, bytes = words * 8;
+        // straight into the workspace planes: the check then runs in place, without the device-side copy
+        LSR_HIP(hipMemcpyAsync(p.work.ptr, a + off, bytes, hipMemcpyHostToDevice, p.stream));
+        LSR_HIP(hipMemcpyAsync(p.work.ptr + words, b + off, bytes, hipMemcpyHostToDevice, p.stream));
+        LSR_HIP(hipMemcpyAsync(p.work.ptr + 2 * words, c + off, bytes, hipMemcpyHostToDevice, p.stream));
+        quotient_pass(p, p.work.ptr, p.work.ptr + words, p.work.ptr + 2 * words, now, p.io.ptr, p.io_len.ptr, p.stream);
+        LSR_HIP(hipMemcpyAsync(q + off, p.io.ptr, bytes, hipMemcpyDeviceToHost, p.stream));
         LSR_HIP(hipMemcpyAsync(len + done, p.io_len.ptr, now * sizeof(uint32_t), hipMemcpyDeviceToHost, p.stream));
         LSR_HIP(hipStreamSynchronize(p.stream));
     }
@@ -440,7 +440,6 @@ static void prover_run(LsrR1csProver& r, const uint64_t* witnesses, size_t batch
     }
     const CsrView a{r.row_ptr[0].ptr, r.col[0].ptr, r.val[0].ptr}, b{r.row_ptr[1].ptr, r.col[1].ptr, r.val[1].ptr},
         c{r.row_ptr[2].ptr, r.col[2].ptr, r.val[2].ptr};
-    const size_t slot = p.chunk << p.logm;
     for (size_t done = 0; done < batch; done += chunk) {
         const size_t now = std::min(chunk, batch - done);
         const size_t per_vector = now << p.logm, off = done << p.logm;
@@ -452,8 +451,8 @@ static void prover_run(LsrR1csProver& r, const uint64_t* witnesses, size_t batch
             for (int k = 0; k < 3; ++k)
                 LSR_HIP(hipMemcpyAsync(evals[k] + off, p.work.ptr + k * per_vector, per_vector * 8, hipMemcpyDeviceToHost, p.stream));
         } else {
-            quotient_pass(p, p.work.ptr, p.work.ptr + per_vector, p.work.ptr + 2 * per_vector, now, p.io.ptr + 3 * slot, p.io_len.ptr, p.stream);
-            LSR_HIP(hipMemcpyAsync(q + off, p.io.ptr + 3 * slot, per_vector * 8, hipMemcpyDeviceToHost, p.stream));
+            quotient_pass(p, p.work.ptr, p.work.ptr + per_vector, p.work.ptr + 2 * per_vector, now, p.io.ptr, p.io_len.ptr, p.stream);
+            LSR_HIP(hipMemcpyAsync(q + off, p.io.ptr, per_vector * 8, hipMemcpyDeviceToHost, p.stream));
             LSR_HIP(hipMemcpyAsync(len + done, p.io_len.ptr, now * sizeof(uint32_t), hipMemcpyDeviceToHost, p.stream));
         }
         LSR_HIP(hipStreamSynchronize(p.stream));
