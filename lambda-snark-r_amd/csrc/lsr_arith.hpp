@@ -219,7 +219,9 @@ __device__ __forceinline__ uint64_t gold_mul(uint64_t a, uint64_t b) {
     const uint64_t hi_hi = hi >> 32, hi_lo = hi & kGoldEpsilon;
     uint64_t t0 = lo - hi_hi;
     if (lo < hi_hi) t0 -= kGoldEpsilon;                                   // borrow: -2^64 = -(2^32 - 1)
-    const uint64_t t1 = hi_lo * kGoldEpsilon;                             // < 2^64
+    // hi_lo * (2^32 - 1) = (hi_lo << 32) - hi_lo, spelled in 32-bit halves so that it stays off the multiplier
+    const uint32_t h32 = (uint32_t)hi_lo;
+    const uint64_t t1 = ((uint64_t)(h32 - (h32 != 0u)) << 32) | (uint64_t)(0u - h32);
     uint64_t r = t0 + t1;
     if (r < t0) r += kGoldEpsilon;                                        // carry: +2^64 = +(2^32 - 1)
     return r >= kGoldilocks ? r - kGoldilocks : r;
