@@ -189,9 +189,9 @@ template <> struct Flavour<ArithGold> {
 };
 
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
-static void tile_fwd(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
+static void tile_fwd(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* src = nullptr) {
     const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
-    hipLaunchKernelGGL((ntt_tile_forward<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::fwd(c));
+    hipLaunchKernelGGL((ntt_tile_forward<A, LT, RAW_IN, RAW_OUT>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, Flavour<A>::fwd(c), src);
 }
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 static void tile_inv(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* add = nullptr, const uint64_t* pre = nullptr) {
@@ -256,20 +256,20 @@ static void pass_inverse(const NttContext& c, int lt, uint64_t* d, size_t total,
 }
 
 template <class A>
-static void small_forward(const NttContext& c, uint64_t* d, size_t total, hipStream_t s) {
+static void small_forward(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* src) {
     switch (c.logn) {
-        case 1: tile_fwd<A, 1, false, false>(c, d, total, s); break;
-        case 2: tile_fwd<A, 2, false, false>(c, d, total, s); break;
-        case 3: tile_fwd<A, 3, false, false>(c, d, total, s); break;
-        case 4: tile_fwd<A, 4, false, false>(c, d, total, s); break;
-        case 5: tile_fwd<A, 5, false, false>(c, d, total, s); break;
-        case 6: tile_fwd<A, 6, false, false>(c, d, total, s); break;
-        case 7: tile_fwd<A, 7, false, false>(c, d, total, s); break;
-        case 8: tile_fwd<A, 8, false, false>(c, d, total, s); break;
-        case 9: tile_fwd<A, 9, false, false>(c, d, total, s); break;
-        case 10: tile_fwd<A, 10, false, false>(c, d, total, s); break;
-        case 11: tile_fwd<A, 11, false, false>(c, d, total, s); break;
-        default: tile_fwd<A, 12, false, false>(c, d, total, s); break;
+        case 1: tile_fwd<A, 1, false, false>(c, d, total, s, src); break;
+        case 2: tile_fwd<A, 2, false, false>(c, d, total, s, src); break;
+        case 3: tile_fwd<A, 3, false, false>(c, d, total, s, src); break;
+        case 4: tile_fwd<A, 4, false, false>(c, d, total, s, src); break;
+        case 5: tile_fwd<A, 5, false, false>(c, d, total, s, src); break;
+        case 6: tile_fwd<A, 6, false, false>(c, d, total, s, src); break;
+        case 7: tile_fwd<A, 7, false, false>(c, d, total, s, src); break;
+        case 8: tile_fwd<A, 8, false, false>(c, d, total, s, src); break;
+        case 9: tile_fwd<A, 9, false, false>(c, d, total, s, src); break;
+        case 10: tile_fwd<A, 10, false, false>(c, d, total, s, src); break;
+        case 11: tile_fwd<A, 11, false, false>(c, d, total, s, src); break;
+        default: tile_fwd<A, 12, false, false>(c, d, total, s, src); break;
     }
 }
 template <class A>
@@ -302,12 +302,13 @@ static size_t ntt_chunk_bytes() {
 }
 
 template <class A>
-static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s, const uint64_t* add, const uint64_t* pre) {
+static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s, const uint64_t* add, const uint64_t* pre,
+                    const uint64_t* src) {
     const size_t total = batch << c.logn;
     if (total == 0) return;
     if (c.logn <= kTileLog) {
         if (inverse) small_inverse<A>(c, d, total, s, add, pre);
-        else small_forward<A>(c, d, total, s);
+        else small_forward<A>(c, d, total, s, src);
         return;
     }
     // n > 4096: the top 4 (n = 2^17: 5) index bits go through ONE strided round, the low `lt` = 9..12 bits through the
@@ -323,7 +324,7 @@ static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse
         const size_t count = now << c.logn;
         hipStream_t cs = s;
         if (!inverse) {
-            strided<A, false, false, true>(c, base, count, c.logn - r_top, r_top, cs);
+            strided<A, false, false, true>(c, base, count, c.logn - r_top, r_top, cs, src ? src + (first << c.logn) : nullptr);
             pass_forward<A>(c, lt, base, count, cs);
         } else {
             pass_inverse<A>(c, lt, base, count, cs, pre);
@@ -333,12 +334,13 @@ static void run_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse
 }
 
 void launch_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hipStream_t s, const uint64_t* add_on_inverse,
-                const uint64_t* pre_mul_on_inverse) {
+                const uint64_t* pre_mul_on_inverse, const uint64_t* forward_source) {
     const uint64_t* add = inverse ? add_on_inverse : nullptr;
     const uint64_t* pre = inverse ? pre_mul_on_inverse : nullptr;
-    if (c.gold) run_ntt<ArithGold>(c, d, batch, inverse, s, add, pre);
-    else if (c.use_f64) run_ntt<ArithF64>(c, d, batch, inverse, s, add, pre);
-    else run_ntt<ArithU64>(c, d, batch, inverse, s, add, pre);
+    const uint64_t* src = inverse ? nullptr : forward_source;
+    if (c.gold) run_ntt<ArithGold>(c, d, batch, inverse, s, add, pre, src);
+    else if (c.use_f64) run_ntt<ArithF64>(c, d, batch, inverse, s, add, pre, src);
+    else run_ntt<ArithU64>(c, d, batch, inverse, s, add, pre, src);
     LSR_HIP(hipGetLastError());
 }
 

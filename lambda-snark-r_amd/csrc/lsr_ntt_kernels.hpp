@@ -167,9 +167,10 @@ __device__ __forceinline__ void inverse_round(typename A::elem (&v)[kRegs], cons
 // Global and twiddle accesses go through buffer resources: the tile's base sits in SGPRs, each lane carries
 // one byte offset per mapping, register offsets are immediates, and a partial last tile is clipped by the
 // resource's size (loads return 0, stores are dropped).
+// src (optional): read the operands from there instead of `data` (same layout) — an out-of-place first pass.
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restrict__ data, size_t total, ModParams p,
-                                                               const typename A::twid* __restrict__ tw) {
+                                                               const typename A::twid* __restrict__ tw, const uint64_t* __restrict__ src = nullptr) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
     using twid = typename A::twid;
@@ -179,7 +180,9 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restric
     const uint32_t nmask = (1u << p.logn) - 1u;
     const uint32_t block_pos = (uint32_t)(tile_base & nmask);
     const size_t left = total - tile_base;
-    const rsrc_t tile = make_rsrc(data + tile_base, left >= kTile ? kTile * 8u : (uint32_t)left * 8u);
+    const uint32_t tile_bytes = left >= kTile ? kTile * 8u : (uint32_t)left * 8u;
+    const rsrc_t tile = make_rsrc(data + tile_base, tile_bytes);
+    const rsrc_t from = make_rsrc(const_cast<uint64_t*>(src ? src : data) + tile_base, tile_bytes);
     const rsrc_t table = make_rsrc(tw, (uint32_t)sizeof(twid) << p.logn);
     elem v[kRegs];
     twid w[2][kRoundTwiddles];
@@ -189,7 +192,7 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restric
         const uint32_t base = lane_base<LO, R>(t);
         uint64_t raw[kRegs];
 #pragma unroll
-        for (int k = 0; k < kRegs; ++k) raw[k] = buf_load64(tile, base * 8u, reg_offset<LO, R>(k) * 8u);
+        for (int k = 0; k < kRegs; ++k) raw[k] = buf_load64(from, base * 8u, reg_offset<LO, R>(k) * 8u);
         load_round_twiddles<A, LO, R, false, false>(w[0], base, block_pos, nmask, p.logn, table);
 #pragma unroll
         for (int k = 0; k < kRegs; ++k) v[k] = RAW_IN ? elem_from_bits<A>(raw[k]) : A::load(raw[k], p);
@@ -322,6 +325,7 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
 // Its butterfly groups are indexed by the polynomial only, so stage j (register bit j) uses the table entries
 // 2^(R-1-j) + u for every lane of every polynomial: compile-time indices, scalar loads, no VGPRs for twiddles.
 // ADD: canonical residues `add` are added to the outputs in the final store (inverse, last pass only).
+// Forward rounds (ADD is then false): a non-null `add` is the array to READ the operands from (out-of-place first pass).
 template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT, bool ADD>
 __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
                                                                 const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
@@ -335,9 +339,10 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
     const size_t idx0 = ((group >> lo) << (lo + R)) | low;
     elem v[N];
     uint64_t extra[ADD ? N : 1];
+    const uint64_t* const from = (!INVERSE && add != nullptr) ? add : data;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const uint64_t raw = data[idx0 + ((size_t)k << lo)];
+        const uint64_t raw = from[idx0 + ((size_t)k << lo)];
         v[k] = RAW_IN ? elem_from_bits<A>(raw) : A::load(raw, p);
     }
     if constexpr (ADD) {   // the blinding residues travel with the operands, not behind the arithmetic

@@ -35,23 +35,16 @@ __device__ __forceinline__ uint64_t gold_canon(uint64_t x) { return x >= kGoldil
 // with g = A B mod X^m + 1), and the finish Q_j = (2m)^-1 (c^[p] - psi^-j z[p]), p = bitrev(j) — the only place where m
 // words are put in natural order (through LDS).
 
-// copy the constraint evaluations into the workspace (the transforms work in place) and test a_k b_k = c_k on the way
-__global__ void __launch_bounds__(kBlock) load_check_kernel(uint64_t* __restrict__ work, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
-                                                            const uint64_t* __restrict__ c, uint32_t* __restrict__ bad, int logm, size_t per_vector,
-                                                            bool copy) {
+// test a_k b_k = c_k (is_satisfied, r1cs.rs:148-172) — the first transform reads the evaluations where they lie
+__global__ void __launch_bounds__(kBlock) check_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, const uint64_t* __restrict__ c,
+                                                       uint32_t* __restrict__ bad, int logm, size_t per_vector) {
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t base = (size_t)blockIdx.x * kBlock; base < per_vector; base += stride) {   // wave-uniform trip count
         const size_t i = base + threadIdx.x;
         const bool live = i < per_vector;
         bool wrong = false;
         if (live) {
-            const uint64_t x = gold_canon(a[i]), y = gold_canon(b[i]), z = gold_canon(c[i]);
-            if (copy) {   // (false: a, b, c are the workspace planes themselves, already canonical)
-                work[i] = x;
-                work[per_vector + i] = y;
-                work[2 * per_vector + i] = z;
-            }
-            wrong = gold_mul(x, y) != z;
+            wrong = gold_mul(gold_canon(a[i]), gold_canon(b[i])) != gold_canon(c[i]);
         }
         if (logm >= 6) {   // a wavefront's 64 consecutive constraints belong to one instance
             if (__ballot(wrong) && (threadIdx.x & 63) == 0) atomicOr(&bad[i >> logm], 1u);
@@ -224,10 +217,15 @@ static void quotient_pass(LsrQuotientPlan& p, const uint64_t* d_a, const uint64_
     uint32_t* top = p.flags.ptr;
     uint32_t* bad = p.flags.ptr + count;
     LSR_HIP(hipMemsetAsync(p.flags.ptr, 0, 2 * count * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(load_check_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, d_a, d_b, d_c, bad, p.logm, per_vector,
-                       d_a != work);
+    hipLaunchKernelGGL(check_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, d_a, d_b, d_c, bad, p.logm, per_vector);
     if (p.ntt) {
-        launch_ntt(*p.ntt, work, 3 * count, false, s);                                   // interpolation: r1cs.rs:489-491
+        if (d_a == work) {                                                               // interpolation: r1cs.rs:489-491
+            launch_ntt(*p.ntt, work, 3 * count, false, s);
+        } else {   // out of place: the caller's arrays are read, the workspace planes written
+            launch_ntt(*p.ntt, work, count, false, s, nullptr, nullptr, d_a);
+            launch_ntt(*p.ntt, work + per_vector, count, false, s, nullptr, nullptr, d_b);
+            launch_ntt(*p.ntt, work + 2 * per_vector, count, false, s, nullptr, nullptr, d_c);
+        }
         launch_ntt(*p.ntt, work, 2 * count, true, s, nullptr, p.twist.ptr);              // A, B on the coset psi H
         hipLaunchKernelGGL(product_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, work + per_vector, per_vector);   // r1cs.rs:495
         launch_ntt(*p.ntt, work, count, false, s);                                       // back to (twisted, bit-reversed) coefficients

@@ -108,8 +108,10 @@ void destroy_ntt_context(NttContext* ctx);
 // store (the commitment's fused blinding add)
 // pre_mul_on_inverse (optional, NTT_MODULUS contexts): canonical residues [n]; input word i of every polynomial of an
 // inverse transform is multiplied by entry i as it is read
+// forward_source (optional): a forward transform reads its operands from there ([batch][n], canonical) and writes d_data
 void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inverse, hipStream_t stream,
-                const uint64_t* add_on_inverse = nullptr, const uint64_t* pre_mul_on_inverse = nullptr);
+                const uint64_t* add_on_inverse = nullptr, const uint64_t* pre_mul_on_inverse = nullptr,
+                const uint64_t* forward_source = nullptr);
 void launch_pointwise(const NttContext& ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t count,
                       hipStream_t stream);
 // out[b][i] = in[b][bitrev_logn(i)] (out != in)
