@@ -1,0 +1,102 @@
+"""Randomized differential run of the GPU library against the oracle (development aid, not part of the test suite).
+env SECONDS (default 240), SEED.  Prints a line per 50 cases and every mismatch; exit code 1 on any mismatch."""
+import os, sys, time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as entry
+import oracle_binding
+
+pkg = entry.load_package(); lib = pkg._abi.lib(); orc = oracle_binding.load()
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+deadline = time.time() + float(os.environ.get("SECONDS", "240"))
+GOLD = pkg.NTT_MODULUS
+bad = 0; cases = 0
+primes = {}
+
+
+def prime_for(n, bits):
+    key = (n, bits)
+    if key not in primes:
+        primes[key] = orc.L.oracle_largest_prime_1mod(2 * n, bits)
+    return primes[key]
+
+
+def fill(q, shape):
+    kind = rng.integers(0, 5)
+    if kind == 0: return np.full(shape, q - 1, dtype=np.uint64)
+    if kind == 1: return rng.integers(0, 4, size=shape, dtype=np.uint64)
+    if kind == 2:
+        pool = np.array([0, 1, q - 1, q - 2, q // 2, q // 2 + 1], dtype=np.uint64)
+        return pool[rng.integers(0, pool.size, size=shape)]
+    return rng.integers(0, q, size=shape, dtype=np.uint64)
+
+
+def report(what, **kw):
+    global bad
+    bad += 1
+    print("MISMATCH", what, kw, flush=True)
+
+
+while time.time() < deadline:
+    cases += 1
+    which = rng.integers(0, 10)
+    if which < 5:            # negacyclic transforms, both flavours
+        logn = int(rng.integers(1, 18)); n = 1 << logn
+        bits = int(rng.integers(max(logn + 3, 14), 61))
+        q = prime_for(n, bits)
+        if q == 0: continue
+        batch = int(rng.integers(1, 40 if logn <= 12 else 6))
+        mode = int(rng.integers(0, 2))
+        lib.lsr_set_arith_mode(mode)
+        ctx = pkg.NttContext(q, n); lib.lsr_set_arith_mode(0)
+        a = fill(q, (batch, n))
+        f = ctx.forward_batch(a)
+        if not np.array_equal(f, orc.ntt_forward(q, n, a)): report("fwd", q=q, n=n, batch=batch, mode=mode)
+        if not np.array_equal(ctx.inverse_batch(f), a): report("inv", q=q, n=n, batch=batch, mode=mode)
+        g = ctx.inverse_batch(a)
+        if not np.array_equal(g, orc.ntt_inverse(q, n, a)): report("inv-of-arbitrary", q=q, n=n, batch=batch, mode=mode)
+        b = fill(q, n)
+        if not np.array_equal(ctx.mul_pointwise(a[0], b), orc.mul_pointwise(q, n, a[0], b)): report("pointwise", q=q, n=n)
+        ctx.close()
+    elif which < 7:          # cyclic transforms over the prover's field
+        logn = int(rng.integers(1, 18)); n = 1 << logn
+        batch = int(rng.integers(1, 20 if logn <= 12 else 4))
+        t = pkg.CyclicNtt(n)
+        x = fill(GOLD, (batch, n))
+        ev = t.forward(x)
+        if not np.array_equal(ev, np.stack([orc.cyclic_forward(r, GOLD, t.omega) for r in x])): report("cyclic fwd", n=n, batch=batch)
+        if not np.array_equal(t.inverse(ev), x): report("cyclic inv", n=n, batch=batch)
+        t.close()
+    elif which < 9:          # quotients
+        logm = int(rng.integers(0, 10)); m = 1 << logm
+        batch = int(rng.integers(1, 30))
+        a = fill(GOLD, (batch, m)); b = fill(GOLD, (batch, m))
+        c = np.array([[int(x) * int(y) % GOLD for x, y in zip(ra, rb)] for ra, rb in zip(a, b)], dtype=np.uint64)
+        for i in range(batch):
+            if rng.integers(0, 4) == 0:
+                j = int(rng.integers(0, m)); c[i, j] = (int(c[i, j]) + 1) % GOLD
+        plan = pkg.QuotientPlan(m)
+        quot, lens = plan.quotient_batch(a, b, c)
+        for i in range(batch):
+            w, ln = orc.quotient(a[i], b[i], c[i])
+            if lens[i] != ln or (ln and not np.array_equal(quot[i], w)): report("quotient", m=m, i=i, ln=ln, got=int(lens[i]))
+        plan.close()
+    else:                    # commitments
+        n = 1 << int(rng.integers(1, 13)); k = int(rng.integers(1, 5))
+        q = [12289, 17592186044417, 17592169062401, prime_for(n, int(rng.integers(41, 61)))][int(rng.integers(0, 4))]
+        if q == 0: continue
+        seed_key = int(rng.integers(1, 2**62))
+        ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=seed_key)
+        msg = rng.integers(0, 2**20, size=int(rng.integers(0, n + 3)), dtype=np.uint64)
+        seed = int(rng.integers(1, 2**62))
+        com = pkg.Commitment(ctx, msg, seed)
+        want = orc.lwe_commit(q, n, k, 3.19, seed_key, msg % np.uint64(q), seed)     # Commitment::new reduces mod the REQUESTED modulus (commitment.rs:33-36)
+        if not np.array_equal(com.as_words(), want): report("commit", q=q, n=n, k=k, len=len(msg))
+        if not pkg.verify_opening_with_context(ctx, com, (msg % np.uint64(q))[:n]): report("verify", q=q, n=n, k=k)
+        com.free(); ctx.close()
+    if cases % 50 == 0:
+        print(f"{cases} cases, {bad} mismatches, {deadline - time.time():.0f} s left", flush=True)
+print(f"done: {cases} cases, {bad} mismatches", flush=True)
+sys.exit(1 if bad else 0)
