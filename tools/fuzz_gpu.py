@@ -41,7 +41,7 @@ def report(what, **kw):
 
 while time.time() < deadline:
     cases += 1
-    which = rng.integers(0, 10)
+    which = rng.integers(0, 12)
     if which < 5:            # negacyclic transforms, both flavours
         logn = int(rng.integers(1, 18)); n = 1 << logn
         bits = int(rng.integers(max(logn + 3, 14), 61))
@@ -83,6 +83,53 @@ while time.time() < deadline:
             w, ln = orc.quotient(a[i], b[i], c[i])
             if lens[i] != ln or (ln and not np.array_equal(quot[i], w)): report("quotient", m=m, i=i, ln=ln, got=int(lens[i]))
         plan.close()
+    elif which == 10:        # R1CS-level prover: random sparse systems with a constructed satisfying witness
+        m = 1 << int(rng.integers(0, 8)); free = int(rng.integers(1, 12)); nv = free + m
+        a, b, c = [], [], []
+        for i in range(m):
+            for mat in (a, b):
+                for col in rng.choice(free + i, size=min(int(rng.integers(1, 5)), free + i), replace=False):
+                    mat.append((i, int(col), int(rng.integers(0, 2**64, dtype=np.uint64))))
+            c.append((i, free + i, 1))
+        batch = int(rng.integers(1, 8))
+        ws = []
+        for _ in range(batch):
+            z = [int(x) for x in rng.integers(0, GOLD, size=free, dtype=np.uint64)] + [0] * m
+            for i in range(m):
+                az = sum((v % GOLD) * z[col] for (r, col, v) in a if r == i) % GOLD
+                bz = sum((v % GOLD) * z[col] for (r, col, v) in b if r == i) % GOLD
+                z[free + i] = az * bz % GOLD
+            if rng.integers(0, 3) == 0: z[free + int(rng.integers(0, m))] ^= 1
+            ws.append(z)
+        ws = np.array(ws, dtype=np.uint64)
+        pr = pkg.R1csProver(m, nv, a, b, c)
+        ea, eb, ec = pr.compute_constraint_evals(ws)
+        quot, lens = pr.quotient_batch(ws)
+        for i in range(batch):
+            oa, ob, oc = (orc.sparse_mul_vec(mat, m, ws[i], GOLD) for mat in (a, b, c))
+            if not (np.array_equal(ea[i], oa) and np.array_equal(eb[i], ob) and np.array_equal(ec[i], oc)): report("r1cs evals", m=m, i=i)
+            w, ln = orc.quotient(oa, ob, oc)
+            if lens[i] != ln or (ln and not np.array_equal(quot[i], w)): report("r1cs quotient", m=m, i=i)
+        pr.close()
+    elif which == 11:        # batch commit, batch verify, linear combination
+        n = 1 << int(rng.integers(3, 13)); k = int(rng.integers(1, 4))
+        q = [17592169062401, 17592186044417][int(rng.integers(0, 2))]
+        seed_key = int(rng.integers(1, 2**62))
+        ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=seed_key)
+        cnt = int(rng.integers(1, 6)); ml = int(rng.integers(1, min(n, 64) + 1))
+        msgs = rng.integers(0, 2**20, size=(cnt, ml), dtype=np.uint64)
+        seeds = rng.integers(1, 2**62, size=cnt, dtype=np.uint64)
+        coms = pkg.Commitment.batch(ctx, msgs, seeds)
+        for i in range(cnt):
+            if not np.array_equal(coms[i].as_words(), orc.lwe_commit(q, n, k, 3.19, seed_key, msgs[i], int(seeds[i]))): report("batch commit", n=n, k=k, i=i)
+        res = pkg.verify_openings_batch(ctx, coms, msgs)
+        if res != [1] * cnt: report("batch verify", n=n, k=k, res=res)
+        coeffs = [int(x) for x in rng.integers(0, 8, size=cnt)]
+        comb = pkg.Commitment.linear_combine(ctx, coms, coeffs)
+        rc, want = orc.lwe_linear_combine(q, n, k, 3.19, seed_key, [cm.as_words() for cm in coms], coeffs)
+        if rc != 0 or not np.array_equal(comb.as_words(), want): report("linear combine", n=n, k=k, cnt=cnt)
+        for cm in coms + [comb]: cm.free()
+        ctx.close()
     else:                    # commitments
         n = 1 << int(rng.integers(1, 13)); k = int(rng.integers(1, 5))
         q = [12289, 17592186044417, 17592169062401, prime_for(n, int(rng.integers(41, 61)))][int(rng.integers(0, 4))]
