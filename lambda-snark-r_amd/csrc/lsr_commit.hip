@@ -159,13 +159,18 @@ __global__ void __launch_bounds__(256) finish_v_kernel(uint64_t* __restrict__ v,
     }
 }
 
-// acc = (acc + c * x) mod q
-__global__ void __launch_bounds__(256) axpy_mod_kernel(uint64_t* __restrict__ acc, const uint64_t* __restrict__ x, uint64_t c, uint64_t count, ModParams p) {
+// acc[x] = (acc[x] + sum_i coeffs[i] * terms[i][x]) mod q — the linear combination of commitments (K6, commitment.cpp:247-266):
+// every commitment body is read once, the accumulator is read and written once per pass
+__global__ void __launch_bounds__(256) combine_kernel(uint64_t* __restrict__ acc, const uint64_t* __restrict__ terms, const uint64_t* __restrict__ coeffs,
+                                                       uint32_t count, uint64_t words, ModParams p) {
     const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
-        uint64_t s = acc[i] + mulmod_barrett128(c, x[i], p);
-        if (s >= p.q) s -= p.q;
-        acc[i] = s;
+    for (uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x; x < words; x += stride) {
+        uint64_t s = acc[x];
+        for (uint32_t i = 0; i < count; ++i) {
+            s += mulmod_barrett128(coeffs[i], terms[(uint64_t)i * words + x], p);
+            if (s >= p.q) s -= p.q;
+        }
+        acc[x] = s;
     }
 }
 
@@ -398,6 +403,16 @@ static void mlwe_matvec_device(const LweContext& c, uint64_t* d_r, const uint64_
     launch_ntt(*c.ntt, d_u, batch * k, true, s, d_e1);
 }
 
+// pinned host staging (guarded by c.mutex), grown on demand
+static void ensure_host_stage(const LweContext& c, size_t words) {
+    if (words <= c.host_stage_words) return;
+    if (c.host_stage) (void)hipHostFree(c.host_stage);
+    c.host_stage = nullptr;
+    c.host_stage_words = 0;
+    LSR_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host_stage), words * 8, hipHostMallocDefault));
+    c.host_stage_words = words;
+}
+
 static LweCommitment* new_commitment(size_t words) {
     auto* out = new LweCommitment;
     out->len = words;
@@ -438,13 +453,7 @@ static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t m
     // (which the ABI wants as separate new[] allocations, commitment.cpp:50-57) are filled from there by a few threads
     const size_t words = kHeaderWords + kn + n;
     const size_t stage_words = batch * (kn + n);
-    if (stage_words > c.host_stage_words) {
-        if (c.host_stage) (void)hipHostFree(c.host_stage);
-        c.host_stage = nullptr;
-        c.host_stage_words = 0;
-        LSR_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host_stage), stage_words * 8, hipHostMallocDefault));
-        c.host_stage_words = stage_words;
-    }
+    ensure_host_stage(c, stage_words);
     uint64_t* const stage_u = c.host_stage;
     uint64_t* const stage_v = c.host_stage + batch * kn;
     LSR_HIP(hipMemcpyAsync(stage_u, c.ws_u.ptr, batch * kn * 8, hipMemcpyDeviceToHost, s));
@@ -589,11 +598,26 @@ static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** 
     const size_t body_words = (size_t)(c.k + 1) * c.n;
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
-    ensure_workspace(c, 1);
     hipStream_t s = c.ntt->stream;
-    DeviceBuffer<uint64_t> acc(body_words), term(body_words);
+    // bodies are gathered `group` at a time (<= 64 MiB) in pinned memory, uploaded in one copy and folded in by one kernel
+    const size_t group = std::max<size_t>(1, std::min<size_t>(count, (size_t(64) << 20) / (body_words * 8)));
+    DeviceBuffer<uint64_t> acc(body_words), terms(group * body_words), d_coeffs(group);
+    ensure_host_stage(c, group * (body_words + 1));
+    uint64_t* const h_terms = c.host_stage;
+    uint64_t* const h_coeffs = c.host_stage + group * body_words;
     LSR_HIP(hipMemsetAsync(acc.ptr, 0, body_words * 8, s));
     bool any = false;
+    size_t staged = 0;
+    auto flush = [&] {
+        if (!staged) return;
+        LSR_HIP(hipMemcpyAsync(terms.ptr, h_terms, staged * body_words * 8, hipMemcpyHostToDevice, s));
+        LSR_HIP(hipMemcpyAsync(d_coeffs.ptr, h_coeffs, staged * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(combine_kernel, dim3(grid_for(body_words)), dim3(256), 0, s, acc.ptr, terms.ptr, d_coeffs.ptr, (uint32_t)staged,
+                           (uint64_t)body_words, c.ntt->mod);
+        LSR_HIP(hipGetLastError());
+        LSR_HIP(hipStreamSynchronize(s));   // the staging is reused
+        staged = 0;
+    };
     for (size_t i = 0; i < count; ++i) {
         if (!cms[i]) continue;                                             // commitment.cpp:248-250
         const uint64_t* body = nullptr;
@@ -601,12 +625,12 @@ static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** 
             (void)hipStreamSynchronize(s);
             return nullptr;                                                // commitment.cpp:253-255
         }
-        LSR_HIP(hipMemcpyAsync(term.ptr, body, body_words * 8, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(axpy_mod_kernel, dim3(grid_for(body_words)), dim3(256), 0, s, acc.ptr, term.ptr, coeffs[i] % c.t, (uint64_t)body_words, c.ntt->mod);
-        LSR_HIP(hipGetLastError());
-        LSR_HIP(hipStreamSynchronize(s));   // `term` is reused
+        std::memcpy(h_terms + staged * body_words, body, body_words * 8);
+        h_coeffs[staged] = coeffs[i] % c.t;
         any = true;
+        if (++staged == group) flush();
     }
+    flush();
     if (!any) return nullptr;                                              // commitment.cpp:268-270
     const size_t words = kHeaderWords + body_words;
     LweCommitment* out = new_commitment(words);

@@ -28,6 +28,11 @@ arr = (ctypes.POINTER(pkg._abi.LweCommitment) * 2)(c1, c2); cf = np.array([2, 3]
 def comb():
     p = lib.lwe_linear_combine(lctx.handle, arr, cf.ctypes.data, 2); lib.lwe_commitment_free(p)
 print(f"lwe_linear_combine (2 terms) : {bench(comb):8.1f} us")
+many = [lib.lwe_commit(lctx.handle, msg.ctypes.data, msg.size, 100 + i) for i in range(256)]
+arr256 = (ctypes.POINTER(pkg._abi.LweCommitment) * 256)(*many); cf256 = np.arange(256, dtype=np.uint64) % 3
+def comb256():
+    p = lib.lwe_linear_combine(lctx.handle, arr256, cf256.ctypes.data, 256); lib.lwe_commitment_free(p)
+print(f"lwe_linear_combine (256 terms): {bench(comb256, 20):8.1f} us")
 buf = np.zeros(4096, dtype=np.uint64)
 print(f"sample_gaussian(4096)        : {bench(lambda: lib.sample_gaussian(buf.ctypes.data, 4096, 3.19), 50):8.1f} us")
 # full commitments (u and v, sampling included, words returned to the host) at the reference's parameters
