@@ -207,23 +207,27 @@ constexpr uint64_t kGoldilocks = 0xFFFFFFFF00000001ull;
 constexpr uint64_t kGoldEpsilon = 0xFFFFFFFFull;   // 2^32 - 1 = 2^64 mod p
 
 __device__ __forceinline__ uint64_t gold_add(uint64_t a, uint64_t b) {   // a, b < p
-    const uint64_t s = a + b;
-    return (s < a || s >= kGoldilocks) ? s - kGoldilocks : s;           // on carry, s - p wraps to the right residue
+    unsigned long long s;
+    const bool carry = __builtin_uaddll_overflow(a, b, &s);
+    return (carry || s >= kGoldilocks) ? s - kGoldilocks : s;              // on carry, s - p wraps to the right residue
 }
 __device__ __forceinline__ uint64_t gold_sub(uint64_t a, uint64_t b) {
-    return a >= b ? a - b : a + kGoldilocks - b;
+    unsigned long long d;
+    const bool borrow = __builtin_usubll_overflow(a, b, &d);
+    return borrow ? d + kGoldilocks : d;
 }
 __device__ __forceinline__ uint64_t gold_mul(uint64_t a, uint64_t b) {
     const unsigned __int128 wide = (unsigned __int128)a * b;
     const uint64_t lo = (uint64_t)wide, hi = (uint64_t)(wide >> 64);
-    const uint64_t hi_hi = hi >> 32, hi_lo = hi & kGoldEpsilon;
-    uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= kGoldEpsilon;                                   // borrow: -2^64 = -(2^32 - 1)
-    // hi_lo * (2^32 - 1) = (hi_lo << 32) - hi_lo, spelled in 32-bit halves so that it stays off the multiplier
-    const uint32_t h32 = (uint32_t)hi_lo;
+    unsigned long long t0;
+    const bool borrow = __builtin_usubll_overflow(lo, hi >> 32, &t0);      // hi_hi 2^96 = -hi_hi
+    t0 -= borrow ? kGoldEpsilon : 0ull;                                    // borrow: -2^64 = -(2^32 - 1)
+    // hi_lo * 2^64 = hi_lo * (2^32 - 1) = (hi_lo << 32) - hi_lo, spelled in 32-bit halves so that it stays off the multiplier
+    const uint32_t h32 = (uint32_t)hi;
     const uint64_t t1 = ((uint64_t)(h32 - (h32 != 0u)) << 32) | (uint64_t)(0u - h32);
-    uint64_t r = t0 + t1;
-    if (r < t0) r += kGoldEpsilon;                                        // carry: +2^64 = +(2^32 - 1)
+    unsigned long long r;
+    const bool carry = __builtin_uaddll_overflow(t0, t1, &r);
+    r += carry ? kGoldEpsilon : 0ull;                                      // carry: +2^64 = +(2^32 - 1)
     return r >= kGoldilocks ? r - kGoldilocks : r;
 }
 
