@@ -8,6 +8,8 @@
 #include <vector>
 #include <string>
 
+#include "lsr_arith.hpp"   // the library's Goldilocks arithmetic (tools/Makefile adds the include path)
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 constexpr int ILP = 8;
@@ -116,6 +118,24 @@ __global__ void __launch_bounds__(256) k_bfly_f64(uint64_t* out, double q, doubl
     out[t] = (uint64_t)acc;
 }
 
+// (G) Goldilocks (2^64 - 2^32 + 1) butterfly of the prover path: the library's gold_mul / gold_add / gold_sub.
+__global__ void __launch_bounds__(256) k_bfly_gold(uint64_t* out, uint64_t w) {
+    uint64_t X[ILP], Y[ILP];
+    const uint64_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = 0; i < ILP; ++i) { X[i] = (t * 0x9E3779B97F4A7C15ull + i) >> 1; Y[i] = (t * 0xBF58476D1CE4E5B9ull + 7 * i) >> 1; }
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) {
+            const uint64_t r = lsr::gold_mul(Y[i], w), x = X[i];
+            X[i] = lsr::gold_add(x, r);
+            Y[i] = lsr::gold_sub(x, r);
+        }
+    }
+    uint64_t acc = 0;
+    for (int i = 0; i < ILP; ++i) acc += X[i] ^ Y[i];
+    out[t] = acc;
+}
+
 // (C) FP64 butterfly using magic-constant rounding instead of v_rndne.
 __global__ void __launch_bounds__(256) k_bfly_f64_magic(uint64_t* out, double q, double w, double invq) {
     double X[ILP], Y[ILP];
@@ -202,6 +222,7 @@ int main() {
     timeit("bfly shoup u64 (Harvey)", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_shoup, dim3(g), dim3(b), 0, 0, d_out, q, w, wq); });
     timeit("bfly shoup trunc u64", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_shoup_trunc, dim3(g), dim3(b), 0, 0, d_out, q, w, wq); });
     timeit("bfly f64 rndne", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_f64, dim3(g), dim3(b), 0, 0, d_out, (double)q, (double)w, 1.0 / (double)q); });
+    timeit("bfly goldilocks u64", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_gold, dim3(g), dim3(b), 0, 0, d_out, 0x0123456789ABCDEFull); });
     timeit("bfly f64 magic", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_f64_magic, dim3(g), dim3(b), 0, 0, d_out, (double)q, (double)w, 1.0 / (double)q); });
     printf("one n=2^16 NTT = 524288 butterflies: NTT/s = bfly_Gops * 1e9 / 524288\n");
     CK(hipFree(d_out));
