@@ -45,6 +45,8 @@ TwiddleTables build_twiddles(uint64_t q, uint32_t n, int logn, uint64_t psi);
 // Output of the forward network is f(omega^bitrev(i)) at slot i.
 constexpr uint64_t kProverModulus = 0xFFFFFFFF00000001ull;       // NTT_MODULUS, lambda-snark-core/src/lib.rs:58
 constexpr uint64_t kProverRoot2_32 = 1753635133440165772ull;     // NTT_PRIMITIVE_ROOT, lib.rs:78
+// Montgomery form w 2^64 mod NTT_MODULUS of a residue: how the Goldilocks kernels hold their multipliers (gold_mul_mont)
+inline uint64_t prover_montgomery(uint64_t w) { return mulmod(w % kProverModulus, 0xFFFFFFFFull, kProverModulus); }   // 2^64 = 2^32 - 1
 // n = 2^k in [2, 131072], prime q (q = NTT_MODULUS or q < 2^61), omega of exact order n.
 bool cyclic_params_valid(uint64_t q, uint32_t n, uint64_t omega, int* logn_out);
 // omega_n of compute_root_of_unity (ntt.rs:226-233); 0 unless q = NTT_MODULUS

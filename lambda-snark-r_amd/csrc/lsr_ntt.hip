@@ -89,11 +89,16 @@ static NttContext* build_context(const char* where, uint64_t q, uint32_t n, int 
         ctx->mod = make_mod_params(q, logn);
         ctx->use_f64 = !ctx->gold && (q < (1ull << 45)) && arith_mode() != 1;
         const uint64_t w_last_scaled = mulmod(tw.inv[n > 1 ? 1 : 0], tw.n_inv, q);
-        if (ctx->gold) {
-            ctx->fwd_gold.upload(tw.fwd);
-            ctx->inv_gold.upload(tw.inv);
-            ctx->n_inv_gold = tw.n_inv;
-            ctx->w_last_scaled_gold = w_last_scaled;
+        if (ctx->gold) {   // multipliers in Montgomery form (gold_mul_mont)
+            std::vector<uint64_t> f(n), g(n);
+            for (uint32_t i = 0; i < n; ++i) {
+                f[i] = prover_montgomery(tw.fwd[i]);
+                g[i] = prover_montgomery(tw.inv[i]);
+            }
+            ctx->fwd_gold.upload(f);
+            ctx->inv_gold.upload(g);
+            ctx->n_inv_gold = prover_montgomery(tw.n_inv);
+            ctx->w_last_scaled_gold = prover_montgomery(w_last_scaled);
         } else if (ctx->use_f64) {
             std::vector<double> f(n), g(n);
             for (uint32_t i = 0; i < n; ++i) {

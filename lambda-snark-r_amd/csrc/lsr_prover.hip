@@ -61,11 +61,11 @@ __global__ void __launch_bounds__(kBlock) product_kernel(uint64_t* __restrict__ 
 }
 
 // compute_constraint_evals (r1cs.rs:296-304): out[mat][inst][row] = sum_e val[e] * z[inst][col[e]] over the row's CSR run.
-// One lane per (instance, row); blockIdx.y selects the matrix.  Witness words are reduced on the way in.
+// One lane per (instance, row); blockIdx.y selects the matrix.  Witness words may be any 64-bit value (v[col] % modulus).
 struct CsrView {
     const uint32_t* row_ptr;   // [m + 1]
     const uint32_t* col;
-    const uint64_t* val;       // canonical
+    const uint64_t* val;       // value mod q, in Montgomery form
 };
 __global__ void __launch_bounds__(kBlock) constraint_evals_kernel(uint64_t* __restrict__ out, CsrView a, CsrView b, CsrView c,
                                                                   const uint64_t* __restrict__ z, uint32_t n_vars, int logm, size_t per_vector) {
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(kBlock) constraint_evals_kernel(uint64_t* __re
         const uint32_t row = (uint32_t)i & ((1u << logm) - 1u);
         const uint64_t* zi = z + (i >> logm) * n_vars;
         uint64_t acc = 0;
-        for (uint32_t e = mat.row_ptr[row]; e < mat.row_ptr[row + 1]; ++e) acc = gold_add(acc, gold_mul(mat.val[e], gold_canon(zi[mat.col[e]])));
+        for (uint32_t e = mat.row_ptr[row]; e < mat.row_ptr[row + 1]; ++e) acc = gold_add(acc, gold_mul_mont(zi[mat.col[e]], mat.val[e]));
         out[blockIdx.y * per_vector + i] = acc;
     }
 }
@@ -85,7 +85,8 @@ constexpr int kSplitPerThread = kSplitTile / kBlock;
 __device__ __forceinline__ int split_slot(int i) { return i + (i >> 6); }   // one pad word per 64
 
 // z, chat = [instances][m] in bit-reversed order -> quotient[inst][j] = half_m_inv * chat[inst][p] - untwist[p] * z[inst][p],
-// p = bitrev(j), untwist[p] = (2m)^-1 psi^-bitrev(p); and per instance `top` = 1 + highest non-zero index.
+// p = bitrev(j), untwist[p] = (2m)^-1 psi^-bitrev(p) (both multipliers in Montgomery form); and per instance `top` =
+// 1 + highest non-zero index.
 // LOGM_HIGH: m >= 4096, one workgroup moves the 4096 words whose index has a fixed middle field (bits 6..logm-7):
 // 64-word runs on both the read and the write side.
 template <bool LOGM_HIGH>
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(kBlock) finish_quotient_kernel(const uint64_t*
             const int A = wave * kSplitPerThread + r;
             const uint32_t pidx = ((uint32_t)A << (logm - 6)) | (B << 6) | (uint32_t)lane;
             const size_t g = (inst << logm) + pidx;
-            tile[A * 65 + lane] = gold_sub(gold_mul(chat[g], half_m_inv), gold_mul(z[g], untwist[pidx]));
+            tile[A * 65 + lane] = gold_sub(gold_mul_mont(chat[g], half_m_inv), gold_mul_mont(z[g], untwist[pidx]));
         }
         __syncthreads();
         uint32_t best = 0;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(kBlock) finish_quotient_kernel(const uint64_t*
             if (g < total) {
                 const uint32_t j = (uint32_t)p & mmask;
                 const uint32_t nat = logm ? (__brev(j) >> (32 - logm)) : 0u;
-                tile[split_slot((p & ~(int)mmask) | (int)nat)] = gold_sub(gold_mul(chat[g], half_m_inv), gold_mul(z[g], untwist[j]));
+                tile[split_slot((p & ~(int)mmask) | (int)nat)] = gold_sub(gold_mul_mont(chat[g], half_m_inv), gold_mul_mont(z[g], untwist[j]));
             }
         }
         __syncthreads();
@@ -169,9 +170,9 @@ struct LsrQuotientPlan {
     int logm = 0;
     int device = 0;
     NttContext* ntt = nullptr;                // size m, on the conjugate root omega_m^-1 (absent for m = 1)
-    lsr::DeviceBuffer<uint64_t> twist;        // psi^bitrev(p), p < m
-    lsr::DeviceBuffer<uint64_t> untwist;      // (2m)^-1 psi^-bitrev(p), p < m
-    uint64_t half_m_inv = 0;                  // (2m)^-1
+    lsr::DeviceBuffer<uint64_t> twist;        // psi^bitrev(p), p < m                  } all three in Montgomery form
+    lsr::DeviceBuffer<uint64_t> untwist;      // (2m)^-1 psi^-bitrev(p), p < m         } (gold_mul_mont)
+    uint64_t half_m_inv = 0;                  // (2m)^-1                               }
     std::mutex mutex;                         // guards the workspace and `stream`
     lsr::DeviceBuffer<uint64_t> work;         // [3][chunk][m]
     lsr::DeviceBuffer<uint32_t> flags;        // top[chunk], bad[chunk]
@@ -325,11 +326,12 @@ static LsrQuotientPlan* create_plan(uint32_t m, int device) {
         if (m >= 2) {
             const uint64_t psi = prover_root_of_unity(q, 2ull * m), psi_inv = invmod_prime(psi, q);
             std::vector<uint64_t> twist(m), untwist(m);
-            p->half_m_inv = invmod_prime((2ull * m) % q, q);
-            uint64_t up = 1, down = p->half_m_inv;
+            const uint64_t half_m_inv = invmod_prime((2ull * m) % q, q);
+            p->half_m_inv = prover_montgomery(half_m_inv);
+            uint64_t up = 1, down = half_m_inv;
             for (uint32_t j = 0; j < m; ++j) {
-                twist[bit_reverse(j, p->logm)] = up;
-                untwist[bit_reverse(j, p->logm)] = down;
+                twist[bit_reverse(j, p->logm)] = prover_montgomery(up);
+                untwist[bit_reverse(j, p->logm)] = prover_montgomery(down);
                 up = mulmod(up, psi, q);
                 down = mulmod(down, psi_inv, q);
             }
@@ -409,7 +411,7 @@ static LsrR1csProver* create_prover(const SparseMatrix* const mats[3], int devic
             for (size_t e = 0; e < M.n_entries; ++e) {
                 const uint32_t at = cursor[M.entries[e].row]++;
                 cols[at] = M.entries[e].col;
-                vals[at] = M.entries[e].value % kProverModulus;       // mul_vec: val % modulus
+                vals[at] = prover_montgomery(M.entries[e].value);     // mul_vec: val % modulus (held in Montgomery form)
             }
             r->row_ptr[k].upload(ptr);
             if (M.n_entries == 0) { cols.push_back(0); vals.push_back(0); }   // keep the pointers non-null

@@ -106,8 +106,8 @@ void destroy_ntt_context(NttContext* ctx);
 // asynchronous launches on `stream`, data resident on ctx->device
 // add_on_inverse (optional): canonical residues [batch][n] added to the outputs of an inverse transform in its final
 // store (the commitment's fused blinding add)
-// pre_mul_on_inverse (optional, NTT_MODULUS contexts): canonical residues [n]; input word i of every polynomial of an
-// inverse transform is multiplied by entry i as it is read
+// pre_mul_on_inverse (optional, NTT_MODULUS contexts): residues [n] in Montgomery form (prover_montgomery); input word i of
+// every polynomial of an inverse transform is multiplied by entry i as it is read
 // forward_source (optional): a forward transform reads its operands from there ([batch][n], canonical) and writes d_data
 void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inverse, hipStream_t stream,
                 const uint64_t* add_on_inverse = nullptr, const uint64_t* pre_mul_on_inverse = nullptr,
