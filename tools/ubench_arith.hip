@@ -138,14 +138,24 @@ __global__ void __launch_bounds__(256) k_bfly_gold(uint64_t* out, uint64_t w) {
 
 // (H) Goldilocks butterfly with a Montgomery-form twiddle: x * (w 2^64 mod p) reduced with p^-1 = 1 + 2^32 (mod 2^64),
 // no multiplication in the reduction, canonical result.
-static __device__ __forceinline__ uint64_t gold_mul_mont(uint64_t x, uint64_t w_mont) {
-    const unsigned __int128 wide = (unsigned __int128)x * w_mont;
-    const uint64_t lo = (uint64_t)wide, hi = (uint64_t)(wide >> 64);
-    const uint64_t m = lo + (lo << 32);                       // lo * p^-1 mod 2^64
-    const uint64_t u = m - (m >> 32) - (uint64_t)(m < (m << 32));   // high word of m * p
-    unsigned long long t;
-    const bool borrow = __builtin_usubll_overflow(hi, u, &t);
-    return borrow ? t + lsr::kGoldilocks : t;
+__global__ void __launch_bounds__(256) k_bfly_gold_lazy(uint64_t* out, uint64_t w) {   // x kept in [0, 2^64), t canonical
+    uint64_t X[ILP], Y[ILP];
+    const uint64_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = 0; i < ILP; ++i) { X[i] = (t * 0x9E3779B97F4A7C15ull + i) >> 1; Y[i] = (t * 0xBF58476D1CE4E5B9ull + 7 * i) >> 1; }
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) {
+            const uint64_t r = lsr::gold_mul_mont(Y[i], w), x = X[i];
+            unsigned long long s, d;
+            const bool c = __builtin_uaddll_overflow(x, r, &s);
+            const bool b = __builtin_usubll_overflow(x, r, &d);
+            X[i] = s + (c ? lsr::kGoldEpsilon : 0ull);
+            Y[i] = d - (b ? lsr::kGoldEpsilon : 0ull);
+        }
+    }
+    uint64_t acc = 0;
+    for (int i = 0; i < ILP; ++i) acc += X[i] ^ Y[i];
+    out[t] = acc;
 }
 __global__ void __launch_bounds__(256) k_bfly_gold_mont(uint64_t* out, uint64_t w) {
     uint64_t X[ILP], Y[ILP];
@@ -154,7 +164,7 @@ __global__ void __launch_bounds__(256) k_bfly_gold_mont(uint64_t* out, uint64_t 
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int i = 0; i < ILP; ++i) {
-            const uint64_t r = gold_mul_mont(Y[i], w), x = X[i];
+            const uint64_t r = lsr::gold_mul_mont(Y[i], w), x = X[i];
             X[i] = lsr::gold_add(x, r);
             Y[i] = lsr::gold_sub(x, r);
         }
@@ -251,6 +261,7 @@ int main() {
     timeit("bfly shoup trunc u64", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_shoup_trunc, dim3(g), dim3(b), 0, 0, d_out, q, w, wq); });
     timeit("bfly f64 rndne", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_f64, dim3(g), dim3(b), 0, 0, d_out, (double)q, (double)w, 1.0 / (double)q); });
     timeit("bfly goldilocks u64", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_gold, dim3(g), dim3(b), 0, 0, d_out, 0x0123456789ABCDEFull); });
+    timeit("bfly goldilocks mont lazy", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_gold_lazy, dim3(g), dim3(b), 0, 0, d_out, 0x0123456789ABCDEFull); });
     timeit("bfly goldilocks montgomery", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_gold_mont, dim3(g), dim3(b), 0, 0, d_out, 0x0123456789ABCDEFull); });
     timeit("bfly f64 magic", per, [&](int g, int b) { hipLaunchKernelGGL(k_bfly_f64_magic, dim3(g), dim3(b), 0, 0, d_out, (double)q, (double)w, 1.0 / (double)q); });
     printf("one n=2^16 NTT = 524288 butterflies: NTT/s = bfly_Gops * 1e9 / 524288\n");
