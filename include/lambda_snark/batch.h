@@ -75,6 +75,13 @@ int lsr_lwe_public_matrix(const LweContext* ctx, uint64_t* a_hat) LSR_NOEXCEPT;
 int lwe_commit_batch(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch,
                      const uint64_t* seeds, LweCommitment** out) LSR_NOEXCEPT;
 
+/* The same `batch` commitments written back to back into ONE caller-owned host array
+ * out_words[batch][lsr_lwe_commitment_words(ctx)] — row i holds exactly the words lwe_commit_batch would put in
+ * out[i]->data (data[0] = payload byte length, commitment.cpp:44-60) — with no per-commitment allocation: the rows are
+ * assembled on the device and come back in one copy.  0 / -1. */
+int lsr_lwe_commit_batch_flat(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch,
+                              const uint64_t* seeds, uint64_t* out_words) LSR_NOEXCEPT;
+
 /* `count` openings in one device pass.  messages = [count][msg_len]; results[i] = 1 / 0 / -1 with the meaning of
  * lwe_verify_opening (cpp-core/src/commitment.cpp:200-232) for (commitments[i], messages[i]); NULL entries => -1.
  * Returns 0, or -1 if the call itself failed. */

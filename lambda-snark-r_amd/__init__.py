@@ -210,6 +210,20 @@ class Commitment:
             raise CoreError("CommitmentFailed: " + _abi.last_error())
         return [cls(ctx, _raw=out[i]) for i in range(msgs.shape[0])]
 
+    @staticmethod
+    def batch_words(ctx, messages, seeds):
+        """``lsr_lwe_commit_batch_flat``: the same commitments as ``batch`` as one [batch][words] array (no per-commitment
+        allocation)."""
+        lib = _abi.lib()
+        msgs = _u64_array(messages, "messages")
+        if msgs.ndim != 2:
+            raise ValueError("messages must be [batch][msg_len]")
+        sd = _u64_array(seeds, "seeds")
+        out = np.zeros((msgs.shape[0], lib.lsr_lwe_commitment_words(ctx.handle)), dtype=np.uint64)
+        if lib.lsr_lwe_commit_batch_flat(ctx.handle, msgs.ctypes.data, msgs.shape[1], msgs.shape[0], sd.ctypes.data, out.ctypes.data) != 0:
+            raise CoreError("CommitmentFailed: " + _abi.last_error())
+        return out
+
     def clone(self):
         p = self._lib.lwe_commitment_clone(self._p)
         if not p:

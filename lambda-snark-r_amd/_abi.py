@@ -102,6 +102,7 @@ SIGNATURES = {
     "lsr_lwe_ntt_context": (vp, [vp]),
     "lsr_lwe_public_matrix": (c_int, [vp, vp]),
     "lwe_commit_batch": (c_int, [vp, vp, c_size, c_size, vp, ctypes.POINTER(ctypes.POINTER(LweCommitment))]),
+    "lsr_lwe_commit_batch_flat": (c_int, [vp, vp, c_size, c_size, vp, vp]),
     "lwe_verify_opening_batch": (c_int, [vp, ctypes.POINTER(ctypes.POINTER(LweCommitment)), vp, c_size, c_size, vp]),
     "lsr_mlwe_matvec_batch_device": (c_int, [vp, vp, vp, vp, c_size, vp, vp]),
     "lsr_fs_challenge": (c_int, [vp, c_size, ctypes.POINTER(LweCommitment), u64, vp, vp]),

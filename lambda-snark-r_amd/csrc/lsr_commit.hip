@@ -254,6 +254,7 @@ struct LweContext {
     mutable lsr::DeviceBuffer<uint64_t> ws_r, ws_e1, ws_e2, ws_u, ws_v, ws_dm, ws_seeds;
     mutable lsr::DeviceBuffer<unsigned long long> ws_flag;
     mutable size_t ws_batch = 0;
+    mutable std::vector<uint64_t> ws_seed_host;   // source of an asynchronous upload: must outlive the call that fills it
     // pinned host staging for the gather of a batch (two bulk D2H copies instead of two per commitment)
     mutable uint64_t* host_stage = nullptr;
     mutable size_t host_stage_words = 0;
@@ -420,13 +421,14 @@ static LweCommitment* new_commitment(size_t words) {
     return out;
 }
 
-static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, LweCommitment** out) {
+// u -> c.ws_u, v -> c.ws_v for `batch` commitments, enqueued on the context's stream
+static void commit_compute(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds) {
     const uint32_t n = c.n, k = c.k;
-    const size_t kn = (size_t)k * n;
     ensure_workspace(c, batch);
     hipStream_t s = c.ntt->stream;
     // host prep: per-commit seeds (0 => fresh entropy, commitment.h:52) and Delta * (m mod t), truncated / zero-padded to n slots
-    std::vector<uint64_t> seed_host(batch);
+    std::vector<uint64_t>& seed_host = c.ws_seed_host;
+    seed_host.resize(batch);
     const size_t copy = std::min<size_t>(msg_len, n);                       // commitment.cpp:146-149
     for (size_t j = 0; j < batch; ++j) seed_host[j] = seeds && seeds[j] ? seeds[j] : (os_entropy64() | 1ull);
     LSR_HIP(hipMemcpyAsync(c.ws_seeds.ptr, seed_host.data(), batch * 8, hipMemcpyHostToDevice, s));
@@ -449,6 +451,41 @@ static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t m
     hipLaunchKernelGGL(finish_v_kernel, dim3(grid_for(vcount)), dim3(256), 0, s, c.ws_v.ptr, c.ws_e2.ptr, d_msgs, (uint64_t)msg_len, (uint64_t)copy,
                        (uint32_t)c.logn, vcount, c.delta, c.t, c.q);
     LSR_HIP(hipGetLastError());
+    if (big_msgs.ptr) LSR_HIP(hipStreamSynchronize(s));   // the oversized message buffer dies with this scope
+}
+
+// wire format rows [batch][5 + kn + n] assembled on the device (one contiguous copy back instead of a host-side scatter)
+__global__ void __launch_bounds__(256) pack_commitments_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ u, const uint64_t* __restrict__ v,
+                                                                uint64_t kn, uint64_t n, uint64_t batch, uint64_t q, uint64_t t, uint64_t shape) {
+    const uint64_t words = kHeaderWords + kn + n;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < batch * words; i += stride) {
+        const uint64_t j = i / words, w = i - j * words;
+        uint64_t x;
+        if (w >= kHeaderWords + kn) x = v[j * n + (w - kHeaderWords - kn)];
+        else if (w >= kHeaderWords) x = u[j * kn + (w - kHeaderWords)];
+        else x = w == 0 ? 8ull * (words - 1) : (w == 1 ? kWireMagic : (w == 2 ? shape : (w == 3 ? q : t)));
+        out[i] = x;
+    }
+}
+
+static void commit_chunk_flat(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, uint64_t* out_words) {
+    const uint64_t n = c.n, kn = (uint64_t)c.k * c.n, words = kHeaderWords + kn + n;
+    commit_compute(c, messages, msg_len, batch, seeds);
+    hipStream_t s = c.ntt->stream;
+    DeviceBuffer<uint64_t> packed(batch * words);
+    hipLaunchKernelGGL(pack_commitments_kernel, dim3(grid_for(batch * words)), dim3(256), 0, s, packed.ptr, c.ws_u.ptr, c.ws_v.ptr, kn, n, (uint64_t)batch,
+                       c.q, c.t, n | ((uint64_t)c.k << 32));
+    LSR_HIP(hipGetLastError());
+    LSR_HIP(hipMemcpyAsync(out_words, packed.ptr, batch * words * 8, hipMemcpyDeviceToHost, s));
+    LSR_HIP(hipStreamSynchronize(s));
+}
+
+static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, LweCommitment** out) {
+    const uint32_t n = c.n, k = c.k;
+    const size_t kn = (size_t)k * n;
+    commit_compute(c, messages, msg_len, batch, seeds);
+    hipStream_t s = c.ntt->stream;
     // gather: u and v of the whole chunk come back in two bulk copies into pinned memory; the per-commitment arrays
     // (which the ABI wants as separate new[] allocations, commitment.cpp:50-57) are filled from there by a few threads
     const size_t words = kHeaderWords + kn + n;
@@ -725,6 +762,30 @@ int lwe_commit_batch(LweContext* ctx, const uint64_t* messages, size_t msg_len, 
         return -1;
     } catch (...) {
         std::fprintf(stderr, "lwe_commit error: unknown exception\n");           // commitment.cpp:161-163
+        return -1;
+    }
+}
+
+int lsr_lwe_commit_batch_flat(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds,
+                              uint64_t* out_words) noexcept {
+    if (!ctx || !messages || !out_words) return -1;
+    if (batch == 0) return 0;
+    try {
+        lsr::DeviceGuard guard(ctx->device);
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        const size_t words = lsr::kHeaderWords + ((size_t)ctx->k + 1) * ctx->n;
+        const size_t per_commit = (4 * (size_t)ctx->k + 5) * ctx->n * 8;
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, (1ull << 30) / per_commit));
+        for (size_t done = 0; done < batch; done += chunk) {
+            const size_t now = std::min(chunk, batch - done);
+            lsr::commit_chunk_flat(*ctx, messages + done * msg_len, msg_len, now, seeds ? seeds + done : nullptr, out_words + done * words);
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lsr_lwe_commit_batch_flat: ") + e.what());
+        std::fprintf(stderr, "lwe_commit error: %s\n", e.what());
+        return -1;
+    } catch (...) {
         return -1;
     }
 }

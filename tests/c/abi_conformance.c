@@ -45,6 +45,7 @@ static void test_without_device(void) {
     CHECK(lsr_plain_modulus(4096) == 1032193);
     CHECK(lsr_quotient_plan_create(3, -1) == NULL && lsr_cyclic_ntt_context_create(12289, 8, 5, -1) == NULL);
     CHECK(lsr_quotient_batch(NULL, NULL, NULL, NULL, 1, NULL, NULL) == -1);
+    CHECK(lsr_lwe_commit_batch_flat(NULL, buf, 1, 1, NULL, buf) == -1);
 }
 
 /* cpp-core/tests/test_ntt.cpp */

@@ -215,6 +215,32 @@ def test_commit_batch_matches_single_calls(pkg, oracle):
 
 
 # ---- BASELINE configs -----------------------------------------------------------------------------------
+def test_commit_batch_flat_equals_per_commitment_form(pkg, oracle, lib, monkeypatch):
+    """lsr_lwe_commit_batch_flat: row i = the words of lwe_commit_batch's out[i], also across several device passes."""
+    q, n, k, key = 17592169062401, 1024, 3, 0xABCDE
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=key)
+    rng = np.random.default_rng(31)
+    batch = 37
+    msgs = rng.integers(0, 2**20, size=(batch, 9), dtype=np.uint64)
+    seeds = rng.integers(1, 2**62, size=batch, dtype=np.uint64)
+    flat = pkg.Commitment.batch_words(ctx, msgs, seeds)
+    assert flat.shape == (batch, 5 + (k + 1) * n)
+    coms = pkg.Commitment.batch(ctx, msgs, seeds)
+    for i in range(batch):
+        assert np.array_equal(flat[i], coms[i].as_words())
+        assert np.array_equal(flat[i], oracle.lwe_commit(q, n, k, 3.19, key, msgs[i], int(seeds[i])))
+        assert flat[i, 0] == 8 * (flat.shape[1] - 1)
+    # a row is a valid commitment for the rest of the ABI
+    row = np.ascontiguousarray(flat[5])
+    as_struct = pkg._abi.LweCommitment(row.ctypes.data_as(pkg._abi.u64p), row.size)
+    assert lib.lwe_verify_opening(ctx.handle, ctypes.byref(as_struct), msgs[5].ctypes.data, 9, None) == 1
+    assert lib.lsr_lwe_commit_batch_flat(ctx.handle, msgs.ctypes.data, 9, 0, seeds.ctypes.data, flat.ctypes.data) == 0
+    assert lib.lsr_lwe_commit_batch_flat(None, msgs.ctypes.data, 9, 1, seeds.ctypes.data, flat.ctypes.data) == -1
+    assert lib.lsr_lwe_commit_batch_flat(ctx.handle, msgs.ctypes.data, 9, 1, seeds.ctypes.data, None) == -1
+    for c in coms: c.free()
+    ctx.close()
+
+
 def test_config1_tv0_linear_system_plumbing(pkg, oracle, golden_dir):
     """Config 1: lwe_context_create{RING_B,128,q,4096,2,3.19} -> statement/witness of
     TV-0 -> one lwe_commit -> lwe_verify_opening == 1.  (The published TV-0 data is itself inconsistent:

@@ -46,3 +46,9 @@ def cb():
 cb()
 t0 = time.perf_counter(); cb(); dt = time.perf_counter() - t0
 print(f"lwe_commit_batch n=4096 k=2 x{batch} (host words out): {dt*1e3:.1f} ms = {batch/dt/1e3:.1f} K commits/s  (reference: ~0.2 K commits/s/core implied, BASELINE.md §2)")
+flat = np.zeros((batch, lib.lsr_lwe_commitment_words(lctx.handle)), dtype=np.uint64)
+def cf():
+    assert lib.lsr_lwe_commit_batch_flat(lctx.handle, msgs.ctypes.data, 8, batch, seeds.ctypes.data, flat.ctypes.data) == 0
+t = bench(cf, 5)
+print(f"lsr_lwe_commit_batch_flat n=4096 k=2 x{batch} (one host array out): {t/1e3:.1f} ms = {batch/t*1e3:.1f} K commits/s")
+
