@@ -87,6 +87,9 @@ int lsr_lwe_commit_batch_flat(LweContext* ctx, const uint64_t* messages, size_t 
  * Returns 0, or -1 if the call itself failed. */
 int lwe_verify_opening_batch(const LweContext* ctx, const LweCommitment* const* commitments, const uint64_t* messages,
                              size_t msg_len, size_t count, int* results) LSR_NOEXCEPT;
+/* The same for `count` commitments stored back to back (rows of lsr_lwe_commit_batch_flat): words[count][lsr_lwe_commitment_words]. */
+int lsr_lwe_verify_opening_batch_flat(const LweContext* ctx, const uint64_t* words, const uint64_t* messages,
+                                      size_t msg_len, size_t count, int* results) LSR_NOEXCEPT;
 
 /* The Module-LWE matrix–vector workload of BASELINE config 3, device-resident:
  *   u_j = INTT( A_hat^T . NTT(r_j) ) + e1_j   for j < batch;   r, e1, u are [batch][k][n] in [0,q).

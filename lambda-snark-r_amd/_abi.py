@@ -104,6 +104,7 @@ SIGNATURES = {
     "lwe_commit_batch": (c_int, [vp, vp, c_size, c_size, vp, ctypes.POINTER(ctypes.POINTER(LweCommitment))]),
     "lsr_lwe_commit_batch_flat": (c_int, [vp, vp, c_size, c_size, vp, vp]),
     "lwe_verify_opening_batch": (c_int, [vp, ctypes.POINTER(ctypes.POINTER(LweCommitment)), vp, c_size, c_size, vp]),
+    "lsr_lwe_verify_opening_batch_flat": (c_int, [vp, vp, vp, c_size, c_size, vp]),
     "lsr_mlwe_matvec_batch_device": (c_int, [vp, vp, vp, vp, c_size, vp, vp]),
     "lsr_fs_challenge": (c_int, [vp, c_size, ctypes.POINTER(LweCommitment), u64, vp, vp]),
     "lsr_minimal_primitive_root": (u64, [u64, u32]),

@@ -579,42 +579,35 @@ static int verify_opening(const LweContext& c, const LweCommitment* cm, const ui
 }
 
 // Many openings in one device pass.  results[i]: 1 / 0 / -1 exactly as the single call.
-static void verify_opening_batch(const LweContext& c, const LweCommitment* const* cms, const uint64_t* messages, size_t msg_len, size_t count,
-                                 int* results) {
+// bodies[i] = the (k + 1) n residues u || v of opening i (already known to belong to this context); results for the
+// `live` indices only.  Bodies are gathered in pinned memory `chunk` at a time and go up in one copy.
+static void verify_bodies(const LweContext& c, const std::vector<const uint64_t*>& bodies, const std::vector<size_t>& live, const uint64_t* messages,
+                          size_t msg_len, int* results) {
     const uint32_t n = c.n, k = c.k;
-    const size_t kn = (size_t)k * n;
-    std::vector<size_t> live;           // indices that reach the device
-    std::vector<const uint64_t*> bodies;
-    for (size_t i = 0; i < count; ++i) {
-        const uint64_t* body = nullptr;
-        if (!cms[i] || !parse_commitment(c, cms[i], &body)) { results[i] = -1; continue; }
-        bool canonical = true;
-        for (size_t x = 0; x < kn + n && canonical; ++x) canonical = body[x] < c.q;
-        if (!canonical) { results[i] = -1; continue; }
-        if (msg_len > n) { results[i] = 0; continue; }
-        if (msg_len == 0) { results[i] = 1; continue; }
-        live.push_back(i);
-        bodies.push_back(body);
-    }
-    if (live.empty()) return;
+    const size_t kn = (size_t)k * n, body_words = kn + n;
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
     hipStream_t s = c.ntt->stream;
-    const size_t per_opening = (3 * (size_t)k + 3) * n * 8;
+    const size_t per_opening = (4 * (size_t)k + 4) * n * 8;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(live.size(), (1ull << 30) / per_opening));
     ensure_workspace(c, chunk);
+    ensure_host_stage(c, chunk * (body_words + msg_len));
+    uint64_t* const h_bodies = c.host_stage;
+    uint64_t* const h_msgs = c.host_stage + chunk * body_words;
     DeviceBuffer<unsigned long long> flags(chunk);
-    DeviceBuffer<uint64_t> d_msgs(chunk * msg_len);
+    DeviceBuffer<uint64_t> d_msgs(chunk * msg_len), d_bodies(chunk * body_words);
     std::vector<unsigned long long> host_flags(chunk);
-    std::vector<uint64_t> host_msgs(chunk * msg_len);
     for (size_t first = 0; first < live.size(); first += chunk) {
         const size_t now = std::min(chunk, live.size() - first);
         for (size_t j = 0; j < now; ++j) {
-            LSR_HIP(hipMemcpyAsync(c.ws_u.ptr + j * kn, bodies[first + j], kn * 8, hipMemcpyHostToDevice, s));
-            LSR_HIP(hipMemcpyAsync(c.ws_v.ptr + j * n, bodies[first + j] + kn, (size_t)n * 8, hipMemcpyHostToDevice, s));
-            std::memcpy(host_msgs.data() + j * msg_len, messages + live[first + j] * msg_len, msg_len * 8);
+            std::memcpy(h_bodies + j * body_words, bodies[first + j], body_words * 8);
+            std::memcpy(h_msgs + j * msg_len, messages + live[first + j] * msg_len, msg_len * 8);
         }
-        LSR_HIP(hipMemcpyAsync(d_msgs.ptr, host_msgs.data(), now * msg_len * 8, hipMemcpyHostToDevice, s));
+        LSR_HIP(hipMemcpyAsync(d_bodies.ptr, h_bodies, now * body_words * 8, hipMemcpyHostToDevice, s));
+        LSR_HIP(hipMemcpyAsync(d_msgs.ptr, h_msgs, now * msg_len * 8, hipMemcpyHostToDevice, s));
+        // u || v rows -> the [now][k][n] and [now][n] arrays the kernels take
+        LSR_HIP(hipMemcpy2DAsync(c.ws_u.ptr, kn * 8, d_bodies.ptr, body_words * 8, kn * 8, now, hipMemcpyDeviceToDevice, s));
+        LSR_HIP(hipMemcpy2DAsync(c.ws_v.ptr, (size_t)n * 8, d_bodies.ptr + kn, body_words * 8, (size_t)n * 8, now, hipMemcpyDeviceToDevice, s));
         LSR_HIP(hipMemsetAsync(flags.ptr, 0, now * sizeof(unsigned long long), s));
         launch_ntt(*c.ntt, c.ws_u.ptr, now * k, false, s);
         launch_ntt(*c.ntt, c.ws_v.ptr, now, false, s);
@@ -629,6 +622,47 @@ static void verify_opening_batch(const LweContext& c, const LweCommitment* const
         LSR_HIP(hipStreamSynchronize(s));
         for (size_t j = 0; j < now; ++j) results[live[first + j]] = host_flags[j] == 0 ? 1 : 0;
     }
+}
+
+// screening shared by the two batched forms: results[i] decided on the host (-1 / 0 / 1), or the opening goes to the device
+static bool screen_opening(const LweContext& c, const uint64_t* body, size_t msg_len, int* result) {
+    const size_t body_words = ((size_t)c.k + 1) * c.n;
+    bool canonical = true;
+    for (size_t x = 0; x < body_words && canonical; ++x) canonical = body[x] < c.q;
+    if (!canonical) { *result = -1; return false; }
+    if (msg_len > c.n) { *result = 0; return false; }
+    if (msg_len == 0) { *result = 1; return false; }
+    return true;
+}
+
+static void verify_opening_batch(const LweContext& c, const LweCommitment* const* cms, const uint64_t* messages, size_t msg_len, size_t count,
+                                 int* results) {
+    std::vector<size_t> live;           // indices that reach the device
+    std::vector<const uint64_t*> bodies;
+    for (size_t i = 0; i < count; ++i) {
+        const uint64_t* body = nullptr;
+        if (!cms[i] || !parse_commitment(c, cms[i], &body)) { results[i] = -1; continue; }
+        if (!screen_opening(c, body, msg_len, &results[i])) continue;
+        live.push_back(i);
+        bodies.push_back(body);
+    }
+    if (!live.empty()) verify_bodies(c, bodies, live, messages, msg_len, results);
+}
+
+// the same for commitments stored back to back (rows of lsr_lwe_commit_batch_flat)
+static void verify_opening_batch_flat(const LweContext& c, const uint64_t* words, const uint64_t* messages, size_t msg_len, size_t count, int* results) {
+    const size_t row = kHeaderWords + ((size_t)c.k + 1) * c.n;
+    std::vector<size_t> live;
+    std::vector<const uint64_t*> bodies;
+    for (size_t i = 0; i < count; ++i) {
+        const LweCommitment view{const_cast<uint64_t*>(words + i * row), row};
+        const uint64_t* body = nullptr;
+        if (!parse_commitment(c, &view, &body)) { results[i] = -1; continue; }
+        if (!screen_opening(c, body, msg_len, &results[i])) continue;
+        live.push_back(i);
+        bodies.push_back(body);
+    }
+    if (!live.empty()) verify_bodies(c, bodies, live, messages, msg_len, results);
 }
 
 static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** cms, const uint64_t* coeffs, size_t count) {
@@ -843,6 +877,22 @@ int lwe_verify_opening_batch(const LweContext* ctx, const LweCommitment* const* 
         return 0;
     } catch (const std::exception& e) {
         lsr::set_last_error(std::string("lwe_verify_opening_batch: ") + e.what());
+        std::fprintf(stderr, "lwe_verify_opening error: %s\n", e.what());
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
+int lsr_lwe_verify_opening_batch_flat(const LweContext* ctx, const uint64_t* words, const uint64_t* messages, size_t msg_len, size_t count,
+                                      int* results) noexcept {
+    if (!ctx || !words || !messages || !results) return -1;
+    if (count == 0) return 0;
+    try {
+        lsr::verify_opening_batch_flat(*ctx, words, messages, msg_len, count, results);
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lsr_lwe_verify_opening_batch_flat: ") + e.what());
         std::fprintf(stderr, "lwe_verify_opening error: %s\n", e.what());
         return -1;
     } catch (...) {

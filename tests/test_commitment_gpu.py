@@ -234,6 +234,15 @@ def test_commit_batch_flat_equals_per_commitment_form(pkg, oracle, lib, monkeypa
     row = np.ascontiguousarray(flat[5])
     as_struct = pkg._abi.LweCommitment(row.ctypes.data_as(pkg._abi.u64p), row.size)
     assert lib.lwe_verify_opening(ctx.handle, ctypes.byref(as_struct), msgs[5].ctypes.data, 9, None) == 1
+    # batched verification straight from the flat rows: a wrong message, a corrupted header and a non-canonical residue
+    res = np.full(batch, 7, dtype=np.int32)
+    wrong = msgs.copy(); wrong[3, 0] += 1
+    rows = flat.copy(); rows[4, 1] ^= 1; rows[6, 10] = q
+    assert lib.lsr_lwe_verify_opening_batch_flat(ctx.handle, rows.ctypes.data, wrong.ctypes.data, 9, batch, res.ctypes.data) == 0
+    want = np.ones(batch, dtype=np.int32); want[3] = 0; want[4] = -1; want[6] = -1
+    assert np.array_equal(res, want)
+    assert pkg.verify_openings_batch(ctx, coms, wrong) == [1, 1, 1, 0] + [1] * (batch - 4)
+    assert lib.lsr_lwe_verify_opening_batch_flat(ctx.handle, None, wrong.ctypes.data, 9, batch, res.ctypes.data) == -1
     assert lib.lsr_lwe_commit_batch_flat(ctx.handle, msgs.ctypes.data, 9, 0, seeds.ctypes.data, flat.ctypes.data) == 0
     assert lib.lsr_lwe_commit_batch_flat(None, msgs.ctypes.data, 9, 1, seeds.ctypes.data, flat.ctypes.data) == -1
     assert lib.lsr_lwe_commit_batch_flat(ctx.handle, msgs.ctypes.data, 9, 1, seeds.ctypes.data, None) == -1

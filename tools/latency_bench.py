@@ -51,4 +51,15 @@ def cf():
     assert lib.lsr_lwe_commit_batch_flat(lctx.handle, msgs.ctypes.data, 8, batch, seeds.ctypes.data, flat.ctypes.data) == 0
 t = bench(cf, 5)
 print(f"lsr_lwe_commit_batch_flat n=4096 k=2 x{batch} (one host array out): {t/1e3:.1f} ms = {batch/t*1e3:.1f} K commits/s")
+res = np.zeros(batch, dtype=np.int32)
+def vf():
+    assert lib.lsr_lwe_verify_opening_batch_flat(lctx.handle, flat.ctypes.data, msgs.ctypes.data, 8, batch, res.ctypes.data) == 0
+t = bench(vf, 5)
+assert (res == 1).all()
+print(f"lsr_lwe_verify_opening_batch_flat x{batch}: {t/1e3:.1f} ms = {batch/t*1e3:.1f} K openings/s")
+assert lib.lwe_commit_batch(lctx.handle, msgs.ctypes.data, 8, batch, seeds.ctypes.data, out) == 0
+def vb():
+    assert lib.lwe_verify_opening_batch(lctx.handle, out, msgs.ctypes.data, 8, batch, res.ctypes.data) == 0
+t = bench(vb, 5)
+print(f"lwe_verify_opening_batch x{batch} (LweCommitment* array): {t/1e3:.1f} ms = {batch/t*1e3:.1f} K openings/s")
 
