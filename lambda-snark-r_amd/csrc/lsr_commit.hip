@@ -469,6 +469,24 @@ __global__ void __launch_bounds__(256) pack_commitments_kernel(uint64_t* __restr
     }
 }
 
+// the reverse of pack_commitments_kernel with the checks of parse_commitment and the canonicity screening: rows -> u, v;
+// bad[j] != 0 when row j is not a commitment of this context (wrong header) or holds a residue >= q
+__global__ void __launch_bounds__(256) unpack_commitments_kernel(const uint64_t* __restrict__ rows, uint64_t* __restrict__ u, uint64_t* __restrict__ v,
+                                                                  uint32_t* __restrict__ bad, uint64_t kn, uint64_t n, uint64_t batch, uint64_t q, uint64_t t,
+                                                                  uint64_t shape) {
+    const uint64_t words = kHeaderWords + kn + n;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < batch * words; i += stride) {
+        const uint64_t j = i / words, w = i - j * words;
+        const uint64_t x = rows[i];
+        bool ok;
+        if (w >= kHeaderWords + kn) { v[j * n + (w - kHeaderWords - kn)] = x; ok = x < q; }
+        else if (w >= kHeaderWords) { u[j * kn + (w - kHeaderWords)] = x; ok = x < q; }
+        else ok = x == (w == 0 ? 8ull * (words - 1) : (w == 1 ? kWireMagic : (w == 2 ? shape : (w == 3 ? q : t))));
+        if (!ok) atomicOr(&bad[j], 1u);
+    }
+}
+
 static void commit_chunk_flat(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, uint64_t* out_words) {
     const uint64_t n = c.n, kn = (uint64_t)c.k * c.n, words = kHeaderWords + kn + n;
     commit_compute(c, messages, msg_len, batch, seeds);
@@ -649,20 +667,53 @@ static void verify_opening_batch(const LweContext& c, const LweCommitment* const
     if (!live.empty()) verify_bodies(c, bodies, live, messages, msg_len, results);
 }
 
-// the same for commitments stored back to back (rows of lsr_lwe_commit_batch_flat)
+// the same for commitments stored back to back (rows of lsr_lwe_commit_batch_flat): the rows go up as they are, the header
+// and canonicity checks run on the device while the rows are split into the u and v arrays
 static void verify_opening_batch_flat(const LweContext& c, const uint64_t* words, const uint64_t* messages, size_t msg_len, size_t count, int* results) {
-    const size_t row = kHeaderWords + ((size_t)c.k + 1) * c.n;
-    std::vector<size_t> live;
-    std::vector<const uint64_t*> bodies;
-    for (size_t i = 0; i < count; ++i) {
-        const LweCommitment view{const_cast<uint64_t*>(words + i * row), row};
-        const uint64_t* body = nullptr;
-        if (!parse_commitment(c, &view, &body)) { results[i] = -1; continue; }
-        if (!screen_opening(c, body, msg_len, &results[i])) continue;
-        live.push_back(i);
-        bodies.push_back(body);
+    const uint32_t n = c.n, k = c.k;
+    const size_t kn = (size_t)k * n, row = kHeaderWords + kn + n;
+    if (msg_len == 0 || msg_len > n) {   // decided by the screening alone: host path
+        for (size_t i = 0; i < count; ++i) {
+            const LweCommitment view{const_cast<uint64_t*>(words + i * row), row};
+            const uint64_t* body = nullptr;
+            if (!parse_commitment(c, &view, &body)) { results[i] = -1; continue; }
+            (void)screen_opening(c, body, msg_len, &results[i]);
+        }
+        return;
     }
-    if (!live.empty()) verify_bodies(c, bodies, live, messages, msg_len, results);
+    DeviceGuard guard(c.device);
+    std::lock_guard<std::mutex> lock(c.mutex);
+    hipStream_t s = c.ntt->stream;
+    const size_t per_opening = (4 * (size_t)k + 5) * n * 8;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(count, (1ull << 30) / per_opening));
+    ensure_workspace(c, chunk);
+    DeviceBuffer<unsigned long long> flags(chunk);
+    DeviceBuffer<uint32_t> bad(chunk);
+    DeviceBuffer<uint64_t> d_msgs(chunk * msg_len), d_rows(chunk * row);
+    std::vector<unsigned long long> host_flags(chunk);
+    std::vector<uint32_t> host_bad(chunk);
+    for (size_t first = 0; first < count; first += chunk) {
+        const size_t now = std::min(chunk, count - first);
+        LSR_HIP(hipMemcpyAsync(d_rows.ptr, words + first * row, now * row * 8, hipMemcpyHostToDevice, s));
+        LSR_HIP(hipMemcpyAsync(d_msgs.ptr, messages + first * msg_len, now * msg_len * 8, hipMemcpyHostToDevice, s));
+        LSR_HIP(hipMemsetAsync(flags.ptr, 0, now * sizeof(unsigned long long), s));
+        LSR_HIP(hipMemsetAsync(bad.ptr, 0, now * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(unpack_commitments_kernel, dim3(grid_for(now * row)), dim3(256), 0, s, d_rows.ptr, c.ws_u.ptr, c.ws_v.ptr, bad.ptr, (uint64_t)kn,
+                           (uint64_t)n, (uint64_t)now, c.q, c.t, (uint64_t)n | ((uint64_t)k << 32));
+        launch_ntt(*c.ntt, c.ws_u.ptr, now * k, false, s);
+        launch_ntt(*c.ntt, c.ws_v.ptr, now, false, s);
+        matvec(c, c.ws_e2.ptr, c.s_hat.ptr, c.ws_u.ptr, nullptr, 1, k, 0, 1, now, s);            // <s_hat, u_hat>
+        hipLaunchKernelGGL(rsub_mod_kernel, dim3(grid_for(now * n)), dim3(256), 0, s, c.ws_e2.ptr, c.ws_v.ptr, (uint64_t)now * n, c.q);
+        launch_ntt(*c.ntt, c.ws_e2.ptr, now, true, s);
+        const uint64_t lanes = (uint64_t)now * msg_len;
+        hipLaunchKernelGGL(decode_compare_batch_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, c.ws_e2.ptr, d_msgs.ptr, (uint64_t)msg_len,
+                           (uint32_t)c.logn, (uint64_t)now, c.t, c.ntt->mod, flags.ptr);
+        LSR_HIP(hipGetLastError());
+        LSR_HIP(hipMemcpyAsync(host_flags.data(), flags.ptr, now * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipMemcpyAsync(host_bad.data(), bad.ptr, now * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipStreamSynchronize(s));
+        for (size_t j = 0; j < now; ++j) results[first + j] = host_bad[j] ? -1 : (host_flags[j] == 0 ? 1 : 0);
+    }
 }
 
 static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** cms, const uint64_t* coeffs, size_t count) {

@@ -242,6 +242,14 @@ def test_commit_batch_flat_equals_per_commitment_form(pkg, oracle, lib, monkeypa
     want = np.ones(batch, dtype=np.int32); want[3] = 0; want[4] = -1; want[6] = -1
     assert np.array_equal(res, want)
     assert pkg.verify_openings_batch(ctx, coms, wrong) == [1, 1, 1, 0] + [1] * (batch - 4)
+    # message lengths decided by the screening alone (commitment.cpp:207-214): empty message -> 1, longer than n -> 0, bad rows -> -1
+    assert lib.lsr_lwe_verify_opening_batch_flat(ctx.handle, rows.ctypes.data, wrong.ctypes.data, 0, batch, res.ctypes.data) == 0
+    want0 = np.ones(batch, dtype=np.int32); want0[4] = -1; want0[6] = -1
+    assert np.array_equal(res, want0)
+    longer = np.zeros((batch, n + 1), dtype=np.uint64)
+    assert lib.lsr_lwe_verify_opening_batch_flat(ctx.handle, rows.ctypes.data, longer.ctypes.data, n + 1, batch, res.ctypes.data) == 0
+    wantl = np.zeros(batch, dtype=np.int32); wantl[4] = -1; wantl[6] = -1
+    assert np.array_equal(res, wantl)
     assert lib.lsr_lwe_verify_opening_batch_flat(ctx.handle, None, wrong.ctypes.data, 9, batch, res.ctypes.data) == -1
     assert lib.lsr_lwe_commit_batch_flat(ctx.handle, msgs.ctypes.data, 9, 0, seeds.ctypes.data, flat.ctypes.data) == 0
     assert lib.lsr_lwe_commit_batch_flat(None, msgs.ctypes.data, 9, 1, seeds.ctypes.data, flat.ctypes.data) == -1
