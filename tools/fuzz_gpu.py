@@ -124,6 +124,13 @@ while time.time() < deadline:
             if not np.array_equal(coms[i].as_words(), orc.lwe_commit(q, n, k, 3.19, seed_key, msgs[i], int(seeds[i]))): report("batch commit", n=n, k=k, i=i)
         res = pkg.verify_openings_batch(ctx, coms, msgs)
         if res != [1] * cnt: report("batch verify", n=n, k=k, res=res)
+        flat = pkg.Commitment.batch_words(ctx, msgs, seeds)
+        if any(not np.array_equal(flat[i], coms[i].as_words()) for i in range(cnt)): report("flat commit", n=n, k=k)
+        spoiled = msgs.copy(); victim = int(rng.integers(0, cnt)); spoiled[victim, 0] ^= np.uint64(1)
+        out = np.full(cnt, 9, dtype=np.int32)
+        if lib.lsr_lwe_verify_opening_batch_flat(ctx.handle, flat.ctypes.data, spoiled.ctypes.data, ml, cnt, out.ctypes.data) != 0: report("flat verify rc")
+        want = np.ones(cnt, dtype=np.int32); want[victim] = 0
+        if not np.array_equal(out, want): report("flat verify", n=n, k=k, got=out.tolist(), victim=victim)
         coeffs = [int(x) for x in rng.integers(0, 8, size=cnt)]
         comb = pkg.Commitment.linear_combine(ctx, coms, coeffs)
         rc, want = orc.lwe_linear_combine(q, n, k, 3.19, seed_key, [cm.as_words() for cm in coms], coeffs)
