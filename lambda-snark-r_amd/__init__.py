@@ -21,7 +21,7 @@ from ._abi import PROFILE_RING_B, PROFILE_SCALAR_A, LweCommitment, LweOpening, P
 
 __all__ = [
     "NttContext", "LweContext", "Commitment", "Params", "CoreError", "verify_opening_with_context",
-    "sample_gaussian", "verify_openings_batch", "PublicParams", "PROFILE_RING_B", "PROFILE_SCALAR_A",
+    "sample_gaussian", "verify_openings_batch", "verify_openings_words", "PublicParams", "PROFILE_RING_B", "PROFILE_SCALAR_A",
     "CyclicNtt", "QuotientPlan", "R1csProver", "compute_root_of_unity", "NTT_MODULUS", "NTT_PRIMITIVE_ROOT",
 ]
 
@@ -291,6 +291,19 @@ def verify_openings_batch(ctx, commitments, messages):
     out = np.zeros(len(commitments), dtype=np.int32)
     if lib.lwe_verify_opening_batch(ctx.handle, arr, msgs.ctypes.data, msgs.shape[1] if msgs.ndim == 2 else 0, len(commitments), out.ctypes.data) != 0:
         raise CoreError("lwe_verify_opening_batch failed: " + _abi.last_error())
+    return [int(x) for x in out]
+
+
+def verify_openings_words(ctx, words, messages):
+    """``lsr_lwe_verify_opening_batch_flat``: commitments as rows of one array (``Commitment.batch_words``)."""
+    lib = _abi.lib()
+    rows = _u64_array(words, "words")
+    msgs = _u64_array(messages, "messages")
+    count = rows.shape[0] if rows.ndim == 2 else 0
+    out = np.zeros(count, dtype=np.int32)
+    if count and lib.lsr_lwe_verify_opening_batch_flat(ctx.handle, rows.ctypes.data, msgs.ctypes.data, msgs.shape[1] if msgs.ndim == 2 else 0, count,
+                                                       out.ctypes.data) != 0:
+        raise CoreError("lsr_lwe_verify_opening_batch_flat failed: " + _abi.last_error())
     return [int(x) for x in out]
 
 

@@ -242,6 +242,7 @@ def test_commit_batch_flat_equals_per_commitment_form(pkg, oracle, lib, monkeypa
     want = np.ones(batch, dtype=np.int32); want[3] = 0; want[4] = -1; want[6] = -1
     assert np.array_equal(res, want)
     assert pkg.verify_openings_batch(ctx, coms, wrong) == [1, 1, 1, 0] + [1] * (batch - 4)
+    assert pkg.verify_openings_words(ctx, rows, wrong) == [int(x) for x in want]
     # message lengths decided by the screening alone (commitment.cpp:207-214): empty message -> 1, longer than n -> 0, bad rows -> -1
     assert lib.lsr_lwe_verify_opening_batch_flat(ctx.handle, rows.ctypes.data, wrong.ctypes.data, 0, batch, res.ctypes.data) == 0
     want0 = np.ones(batch, dtype=np.int32); want0[4] = -1; want0[6] = -1
