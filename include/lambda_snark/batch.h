@@ -106,6 +106,12 @@ int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uin
  * hash32 may be NULL.  0 / -1. */
 int lsr_fs_challenge(const uint64_t* public_inputs, size_t n_inputs, const LweCommitment* commitment, uint64_t modulus,
                      uint64_t* alpha, uint8_t* hash32) LSR_NOEXCEPT;
+/* `count` transcripts at once: commitments as rows words[count][words_per_commitment] (lsr_lwe_commit_batch_flat), public
+ * inputs [count][n_inputs]; alphas[count], hashes32 (optional) [count][32].  SHA3 is sequential inside a transcript and
+ * independent across them: a pool of `threads` host threads (0 = up to 16) shares the rows.  0 / -1. */
+int lsr_fs_challenge_batch_flat(const uint64_t* public_inputs, size_t n_inputs, const uint64_t* words,
+                                size_t words_per_commitment, size_t count, uint64_t modulus, uint64_t* alphas,
+                                uint8_t* hashes32, unsigned threads) LSR_NOEXCEPT;
 
 /* ---------------- host-only number theory (usable without a GPU) ---------------- */
 uint64_t lsr_minimal_primitive_root(uint64_t q, uint32_t n) LSR_NOEXCEPT;   /* 0 if none */

@@ -129,5 +129,22 @@ def test_fs_challenge_matches_sha3_transcript(lib, pkg):
             assert lib.lsr_fs_challenge(inp.ctypes.data if inputs else None, len(inputs), ctypes.byref(com), q, ctypes.byref(alpha), digest) == 0
             want_alpha, want_hash = prover_replay.challenge_derive(inputs, words, q)
             assert alpha.value == want_alpha and bytes(digest) == want_hash
+    # the batched form: rows of one array, a pool of host threads
+    count, row_words, n_in = 37, 300, 3
+    rows = rng.integers(0, 2**64, size=(count, row_words), dtype=np.uint64)
+    ins = rng.integers(0, 2**64, size=(count, n_in), dtype=np.uint64)
+    alphas = np.zeros(count, dtype=np.uint64); hashes = np.zeros((count, 32), dtype=np.uint8)
+    for threads in (0, 1, 5, 64):
+        alphas[:] = 0; hashes[:] = 0
+        assert lib.lsr_fs_challenge_batch_flat(ins.ctypes.data, n_in, rows.ctypes.data, row_words, count, 17592186044417, alphas.ctypes.data,
+                                               hashes.ctypes.data, threads) == 0
+        for i in range(count):
+            want_alpha, want_hash = prover_replay.challenge_derive([int(x) for x in ins[i]], rows[i], 17592186044417)
+            assert alphas[i] == want_alpha and bytes(hashes[i]) == want_hash
+    assert lib.lsr_fs_challenge_batch_flat(None, 0, rows.ctypes.data, row_words, count, 12289, alphas.ctypes.data, None, 2) == 0
+    assert alphas[0] == prover_replay.challenge_derive([], rows[0], 12289)[0]
+    assert lib.lsr_fs_challenge_batch_flat(None, 2, rows.ctypes.data, row_words, count, 12289, alphas.ctypes.data, None, 2) == -1
+    assert lib.lsr_fs_challenge_batch_flat(None, 0, None, row_words, count, 12289, alphas.ctypes.data, None, 2) == -1
+    assert lib.lsr_fs_challenge_batch_flat(None, 0, rows.ctypes.data, row_words, 0, 12289, alphas.ctypes.data, None, 2) == 0
     assert lib.lsr_fs_challenge(None, 0, None, 12289, ctypes.byref(alpha), None) == -1
     assert lib.lsr_fs_challenge(None, 0, ctypes.byref(com), 0, ctypes.byref(alpha), None) == -1
