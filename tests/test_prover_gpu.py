@@ -316,3 +316,48 @@ def test_r1cs_prover_reference_gates_and_errors(pkg, lib):
     assert list(empty.compute_quotient_poly([5, 6, 7])) == [0]
     assert lib.lsr_r1cs_prover_num_constraints(empty._h) == 4 and lib.lsr_r1cs_prover_num_variables(empty._h) == 3
     gate.close(); two.close(); empty.close()
+
+
+def test_batched_prove_chain_matches_the_one_by_one_replay(pkg, lib, oracle):
+    """prove_r1cs (lib.rs:747-809) for a batch of witnesses of one circuit on the NTT path, chained through the batched entry
+    points — lsr_r1cs_quotient_batch -> lsr_lwe_commit_batch_flat -> lsr_fs_challenge_batch_flat (alpha, then beta) ->
+    lsr_lwe_verify_opening_batch_flat — against the same steps taken one proof at a time with the single-call ABI."""
+    import prover_replay
+    rng = np.random.default_rng(2468)
+    m, free_vars, batch, n_public = 64, 10, 9, 3
+    n, a, b, c = random_r1cs(rng, m, free_vars)
+    ws = np.stack([extend_witness(rng.integers(0, Q, size=free_vars, dtype=np.uint64), m, a, b) for _ in range(batch)])
+    params = pkg.Params(q=17592186044417, n=4096, k=2, sigma=3.19)
+    ctx = pkg.LweContext(params, key_seed=0x5EED)
+    seeds = np.arange(1, batch + 1, dtype=np.uint64) * np.uint64(7919)
+    # --- batched chain ---
+    prover = pkg.R1csProver(m, n, a, b, c)
+    quot, lens = prover.quotient_batch(ws)
+    assert (lens >= 1).all()
+    msgs = quot % np.uint64(params.q)            # Commitment::new reduces mod ctx.modulus() (commitment.rs:33-36)
+    rows = pkg.Commitment.batch_words(ctx, msgs, seeds)
+    publics = np.ascontiguousarray(ws[:, :n_public])
+    alphas = np.zeros(batch, dtype=np.uint64); betas = np.zeros(batch, dtype=np.uint64)
+    ha = np.zeros((batch, 32), dtype=np.uint8); hb = np.zeros((batch, 32), dtype=np.uint8)
+    W = rows.shape[1]
+    assert lib.lsr_fs_challenge_batch_flat(publics.ctypes.data, n_public, rows.ctypes.data, W, batch, Q, alphas.ctypes.data, ha.ctypes.data, 0) == 0
+    assert lib.lsr_fs_challenge_batch_flat(alphas.ctypes.data, 1, rows.ctypes.data, W, batch, Q, betas.ctypes.data, hb.ctypes.data, 0) == 0
+    assert pkg.verify_openings_words(ctx, rows, msgs) == [1] * batch
+    # --- one proof at a time ---
+    for i in range(batch):
+        ea, eb, ec = (oracle.sparse_mul_vec(mat, m, ws[i], Q) for mat in (a, b, c))
+        q_coeffs, ln = oracle.quotient(ea, eb, ec)
+        assert ln == lens[i] and np.array_equal(q_coeffs, quot[i])
+        com = pkg.Commitment(ctx, q_coeffs[:ln], int(seeds[i]))                           # trimmed message: the zero tail encodes the same
+        assert np.array_equal(com.as_words(), rows[i])
+        alpha, h_alpha = prover_replay.challenge_derive([int(x) for x in publics[i]], com.as_words(), Q)
+        beta, h_beta = prover_replay.challenge_derive([alpha], com.as_words(), Q)
+        assert (int(alphas[i]), bytes(ha[i]), int(betas[i]), bytes(hb[i])) == (alpha, h_alpha, beta, h_beta)
+        # verify_r1cs's check (lib.rs:1016-1095) at alpha with the interpolants of the NTT domain
+        w = oracle.prover_omega(m)
+        pa, pb, pc = (oracle.cyclic_inverse(v, Q, w) for v in (ea, eb, ec))
+        lhs = oracle.eval_poly(q_coeffs[:ln], alpha, Q) * ((pow(alpha, m, Q) - 1) % Q) % Q
+        rhs = (oracle.eval_poly(pa, alpha, Q) * oracle.eval_poly(pb, alpha, Q) - oracle.eval_poly(pc, alpha, Q)) % Q
+        assert lhs == rhs
+        com.free()
+    prover.close(); ctx.close()
