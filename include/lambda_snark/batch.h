@@ -81,6 +81,11 @@ int lwe_commit_batch(LweContext* ctx, const uint64_t* messages, size_t msg_len, 
  * assembled on the device and come back in one copy.  0 / -1. */
 int lsr_lwe_commit_batch_flat(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch,
                               const uint64_t* seeds, uint64_t* out_words) LSR_NOEXCEPT;
+/* The same with the rows left in DEVICE memory d_out_words[batch][lsr_lwe_commitment_words(ctx)] on the context's device
+ * (messages and seeds are still host arrays); returns after the rows are complete.  For chaining with
+ * lsr_fs_challenge_batch_device before the rows travel to the host. */
+int lsr_lwe_commit_batch_flat_device(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch,
+                                     const uint64_t* seeds, uint64_t* d_out_words) LSR_NOEXCEPT;
 
 /* `count` openings in one device pass.  messages = [count][msg_len]; results[i] = 1 / 0 / -1 with the meaning of
  * lwe_verify_opening (cpp-core/src/commitment.cpp:200-232) for (commitments[i], messages[i]); NULL entries => -1.
@@ -112,6 +117,13 @@ int lsr_fs_challenge(const uint64_t* public_inputs, size_t n_inputs, const LweCo
 int lsr_fs_challenge_batch_flat(const uint64_t* public_inputs, size_t n_inputs, const uint64_t* words,
                                 size_t words_per_commitment, size_t count, uint64_t modulus, uint64_t* alphas,
                                 uint8_t* hashes32, unsigned threads) LSR_NOEXCEPT;
+/* The same on device-resident arrays (8-byte aligned), one lane per transcript, asynchronous on `stream`: d_words
+ * [count][words_per_commitment] (e.g. from lsr_lwe_commit_batch_flat_device), d_public_inputs [count][n_inputs] (may be a
+ * previous call's d_alphas with n_inputs = 1: the second challenge of prove_r1cs, lib.rs:768), d_alphas [count],
+ * d_hashes32 (optional) [count][32].  The cost is flat up to 65 536 transcripts (a wavefront per SIMD).  0 / -1. */
+int lsr_fs_challenge_batch_device(const uint64_t* d_public_inputs, size_t n_inputs, const uint64_t* d_words,
+                                  size_t words_per_commitment, size_t count, uint64_t modulus, uint64_t* d_alphas,
+                                  uint8_t* d_hashes32, void* stream) LSR_NOEXCEPT;
 
 /* ---------------- host-only number theory (usable without a GPU) ---------------- */
 uint64_t lsr_minimal_primitive_root(uint64_t q, uint32_t n) LSR_NOEXCEPT;   /* 0 if none */

@@ -108,6 +108,8 @@ SIGNATURES = {
     "lsr_mlwe_matvec_batch_device": (c_int, [vp, vp, vp, vp, c_size, vp, vp]),
     "lsr_fs_challenge": (c_int, [vp, c_size, ctypes.POINTER(LweCommitment), u64, vp, vp]),
     "lsr_fs_challenge_batch_flat": (c_int, [vp, c_size, vp, c_size, c_size, u64, vp, vp, ctypes.c_uint]),
+    "lsr_fs_challenge_batch_device": (c_int, [vp, c_size, vp, c_size, c_size, u64, vp, vp, vp]),
+    "lsr_lwe_commit_batch_flat_device": (c_int, [vp, vp, c_size, c_size, vp, vp]),
     "lsr_minimal_primitive_root": (u64, [u64, u32]),
     # r1cs.h (SEAL/NTL-free shim, host only)
     "lambda_snark_r1cs_create": (c_int, [ctypes.POINTER(SparseMatrix), ctypes.POINTER(SparseMatrix), ctypes.POINTER(SparseMatrix), u64, ctypes.POINTER(vp)]),

@@ -487,15 +487,22 @@ __global__ void __launch_bounds__(256) unpack_commitments_kernel(const uint64_t*
     }
 }
 
-static void commit_chunk_flat(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, uint64_t* out_words) {
+// out_words: host array (the rows come back in one copy) or, with `to_device`, device memory the rows are assembled in
+static void commit_chunk_flat(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, uint64_t* out_words,
+                              bool to_device) {
     const uint64_t n = c.n, kn = (uint64_t)c.k * c.n, words = kHeaderWords + kn + n;
     commit_compute(c, messages, msg_len, batch, seeds);
     hipStream_t s = c.ntt->stream;
-    DeviceBuffer<uint64_t> packed(batch * words);
-    hipLaunchKernelGGL(pack_commitments_kernel, dim3(grid_for(batch * words)), dim3(256), 0, s, packed.ptr, c.ws_u.ptr, c.ws_v.ptr, kn, n, (uint64_t)batch,
-                       c.q, c.t, n | ((uint64_t)c.k << 32));
+    DeviceBuffer<uint64_t> packed;
+    uint64_t* rows = out_words;
+    if (!to_device) {
+        packed.allocate(batch * words);
+        rows = packed.ptr;
+    }
+    hipLaunchKernelGGL(pack_commitments_kernel, dim3(grid_for(batch * words)), dim3(256), 0, s, rows, c.ws_u.ptr, c.ws_v.ptr, kn, n, (uint64_t)batch, c.q,
+                       c.t, n | ((uint64_t)c.k << 32));
     LSR_HIP(hipGetLastError());
-    LSR_HIP(hipMemcpyAsync(out_words, packed.ptr, batch * words * 8, hipMemcpyDeviceToHost, s));
+    if (!to_device) LSR_HIP(hipMemcpyAsync(out_words, packed.ptr, batch * words * 8, hipMemcpyDeviceToHost, s));
     LSR_HIP(hipStreamSynchronize(s));
 }
 
@@ -851,8 +858,8 @@ int lwe_commit_batch(LweContext* ctx, const uint64_t* messages, size_t msg_len, 
     }
 }
 
-int lsr_lwe_commit_batch_flat(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds,
-                              uint64_t* out_words) noexcept {
+static int commit_batch_flat(const char* where, LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds,
+                             uint64_t* out_words, bool to_device) noexcept {
     if (!ctx || !messages || !out_words) return -1;
     if (batch == 0) return 0;
     try {
@@ -863,16 +870,25 @@ int lsr_lwe_commit_batch_flat(LweContext* ctx, const uint64_t* messages, size_t 
         const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, (1ull << 30) / per_commit));
         for (size_t done = 0; done < batch; done += chunk) {
             const size_t now = std::min(chunk, batch - done);
-            lsr::commit_chunk_flat(*ctx, messages + done * msg_len, msg_len, now, seeds ? seeds + done : nullptr, out_words + done * words);
+            lsr::commit_chunk_flat(*ctx, messages + done * msg_len, msg_len, now, seeds ? seeds + done : nullptr, out_words + done * words, to_device);
         }
         return 0;
     } catch (const std::exception& e) {
-        lsr::set_last_error(std::string("lsr_lwe_commit_batch_flat: ") + e.what());
+        lsr::set_last_error(std::string(where) + ": " + e.what());
         std::fprintf(stderr, "lwe_commit error: %s\n", e.what());
         return -1;
     } catch (...) {
         return -1;
     }
+}
+
+int lsr_lwe_commit_batch_flat(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds,
+                              uint64_t* out_words) noexcept {
+    return commit_batch_flat("lsr_lwe_commit_batch_flat", ctx, messages, msg_len, batch, seeds, out_words, false);
+}
+int lsr_lwe_commit_batch_flat_device(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds,
+                                     uint64_t* d_out_words) noexcept {
+    return commit_batch_flat("lsr_lwe_commit_batch_flat_device", ctx, messages, msg_len, batch, seeds, d_out_words, true);
 }
 
 LweCommitment* lwe_commit(LweContext* ctx, const uint64_t* message, size_t msg_len, uint64_t seed) noexcept {

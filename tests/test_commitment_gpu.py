@@ -396,3 +396,62 @@ def test_large_combination_coefficients_need_a_wide_modulus(pkg):
     small = pkg.Commitment.linear_combine(narrow, coms, [200, 300, 400])
     assert pkg.verify_opening_with_context(narrow, small, [sum(c * m[i] for c, m in zip([200, 300, 400], msgs)) % t for i in range(4)])
     narrow.close()
+
+
+@pytest.mark.parametrize("row_words,n_inputs", [(1, 0), (5, 2), (13, 0), (14, 1), (15, 3), (16, 0), (30, 17), (31, 40), (300, 3), (12293, 2)])
+def test_device_transcripts_match_hashlib(lib, row_words, n_inputs):
+    """lsr_fs_challenge_batch_device against hashlib's SHA3-256 over the transcript of challenge.rs:102-134 — row lengths
+    around the 136-byte block boundaries, public inputs that spill over several blocks, and the reference-size row."""
+    import torch
+    import prover_replay
+    count = 70 if row_words < 1000 else 5
+    rng = np.random.default_rng(row_words * 131 + n_inputs)
+    rows = rng.integers(0, 2**64, size=(count, row_words), dtype=np.uint64)
+    ins = rng.integers(0, 2**64, size=(count, max(n_inputs, 1)), dtype=np.uint64)[:, :n_inputs]
+    d_rows = torch.from_numpy(rows.view(np.int64)).cuda()
+    d_ins = torch.from_numpy(np.ascontiguousarray(ins).view(np.int64)).cuda() if n_inputs else None
+    d_alpha = torch.zeros(count, dtype=torch.int64, device="cuda")
+    d_hash = torch.zeros((count, 32), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for modulus in (18446744069414584321, 17592186044417, 12289):
+        assert lib.lsr_fs_challenge_batch_device(d_ins.data_ptr() if n_inputs else None, n_inputs, d_rows.data_ptr(), row_words, count, modulus,
+                                                 d_alpha.data_ptr(), d_hash.data_ptr(), s) == 0
+        torch.cuda.synchronize()
+        alphas = d_alpha.cpu().numpy().view(np.uint64); hashes = d_hash.cpu().numpy()
+        for i in range(count):
+            want_alpha, want_hash = prover_replay.challenge_derive([int(x) for x in ins[i]], rows[i], modulus)
+            assert int(alphas[i]) == want_alpha and bytes(hashes[i]) == want_hash, (row_words, n_inputs, i)
+    assert lib.lsr_fs_challenge_batch_device(None, 1, d_rows.data_ptr(), row_words, count, 12289, d_alpha.data_ptr(), None, s) == -1
+    assert lib.lsr_fs_challenge_batch_device(None, 0, d_rows.data_ptr(), row_words, 0, 12289, d_alpha.data_ptr(), None, s) == 0
+    assert lib.lsr_fs_challenge_batch_device(None, 0, d_rows.data_ptr(), row_words, count, 12289, d_alpha.data_ptr(), None, s) == 0   # hashes optional
+
+
+def test_commit_rows_and_both_challenges_stay_on_the_device(pkg, lib, oracle):
+    """lsr_lwe_commit_batch_flat_device -> alpha -> beta (public input = alpha, lib.rs:768) without the rows leaving the GPU."""
+    import torch
+    import prover_replay
+    q, n, k, key = 17592186044417, 4096, 2, 0xFEED
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=key)
+    batch, W = 6, lib.lsr_lwe_commitment_words(ctx.handle)
+    rng = np.random.default_rng(12)
+    msgs = rng.integers(0, 2**20, size=(batch, 7), dtype=np.uint64)
+    seeds = rng.integers(1, 2**62, size=batch, dtype=np.uint64)
+    publics = rng.integers(0, 2**44, size=(batch, 2), dtype=np.uint64)
+    d_rows = torch.zeros((batch, W), dtype=torch.int64, device="cuda")
+    assert lib.lsr_lwe_commit_batch_flat_device(ctx.handle, msgs.ctypes.data, 7, batch, seeds.ctypes.data, d_rows.data_ptr()) == 0
+    d_pub = torch.from_numpy(publics.view(np.int64)).cuda()
+    d_alpha = torch.zeros(batch, dtype=torch.int64, device="cuda"); d_beta = torch.zeros_like(d_alpha)
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.lsr_fs_challenge_batch_device(d_pub.data_ptr(), 2, d_rows.data_ptr(), W, batch, q, d_alpha.data_ptr(), None, s) == 0
+    assert lib.lsr_fs_challenge_batch_device(d_alpha.data_ptr(), 1, d_rows.data_ptr(), W, batch, q, d_beta.data_ptr(), None, s) == 0
+    torch.cuda.synchronize()
+    rows = d_rows.cpu().numpy().view(np.uint64)
+    host_rows = pkg.Commitment.batch_words(ctx, msgs, seeds)
+    assert np.array_equal(rows, host_rows)
+    for i in range(batch):
+        assert np.array_equal(rows[i], oracle.lwe_commit(q, n, k, 3.19, key, msgs[i], int(seeds[i])))
+        alpha, _ = prover_replay.challenge_derive([int(x) for x in publics[i]], rows[i], q)
+        beta, _ = prover_replay.challenge_derive([alpha], rows[i], q)
+        assert (int(d_alpha[i].item()) & (2**64 - 1), int(d_beta[i].item()) & (2**64 - 1)) == (alpha, beta)
+    assert lib.lsr_lwe_commit_batch_flat_device(ctx.handle, msgs.ctypes.data, 7, batch, seeds.ctypes.data, None) == -1
+    ctx.close()
