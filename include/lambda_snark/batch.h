@@ -120,7 +120,8 @@ int lsr_fs_challenge_batch_flat(const uint64_t* public_inputs, size_t n_inputs, 
 /* The same on device-resident arrays (8-byte aligned), one lane per transcript, asynchronous on `stream`: d_words
  * [count][words_per_commitment] (e.g. from lsr_lwe_commit_batch_flat_device), d_public_inputs [count][n_inputs] (may be a
  * previous call's d_alphas with n_inputs = 1: the second challenge of prove_r1cs, lib.rs:768), d_alphas [count],
- * d_hashes32 (optional) [count][32].  The cost is flat up to 65 536 transcripts (a wavefront per SIMD).  0 / -1. */
+ * d_hashes32 (optional) [count][32].  The kernel is launched on the calling thread's current HIP device (where the arrays
+ * must live).  The cost is flat up to 65 536 transcripts (a wavefront per SIMD).  0 / -1. */
 int lsr_fs_challenge_batch_device(const uint64_t* d_public_inputs, size_t n_inputs, const uint64_t* d_words,
                                   size_t words_per_commitment, size_t count, uint64_t modulus, uint64_t* d_alphas,
                                   uint8_t* d_hashes32, void* stream) LSR_NOEXCEPT;
