@@ -220,6 +220,31 @@ def main():
                       "quotient_roofline_frac": qb * qm * 32 / t_q / (HBM_PEAK_GBS * 1e9)})
         plan.close(); field.close()
 
+    # ---- complete commitments at the reference's parameters (n = 4096, k = 2), PCIe included: host-visible throughput of the
+    #      additive flat entry points (never the headline value) ----
+    if not args.no_commit and rank == 0:
+        torch.cuda.empty_cache()
+        rctx = pkg.LweContext(pkg.Params(q=17592186044417, n=4096, k=2, sigma=3.19), key_seed=0xC0DE + 2, device=local)
+        nb = 2048
+        rmsgs = (np.arange(nb * 8, dtype=np.uint64).reshape(nb, 8) * 7919) % 1000003
+        rseeds = np.arange(1, nb + 1, dtype=np.uint64)
+        rows = np.zeros((nb, pkg._abi.lib().lsr_lwe_commitment_words(rctx.handle)), dtype=np.uint64)
+        verdicts = np.zeros(nb, dtype=np.int32)
+        flat_lib = pkg._abi.lib()
+
+        def wall(fn, reps=3):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t0) / reps
+
+        t_c = wall(lambda: flat_lib.lsr_lwe_commit_batch_flat(rctx.handle, rmsgs.ctypes.data, 8, nb, rseeds.ctypes.data, rows.ctypes.data))
+        t_v = wall(lambda: flat_lib.lsr_lwe_verify_opening_batch_flat(rctx.handle, rows.ctypes.data, rmsgs.ctypes.data, 8, nb, verdicts.ctypes.data))
+        extra.update({"ref_params_commits_per_s_pcie": nb / t_c, "ref_params_openings_per_s_pcie": nb / t_v,
+                      "ref_params_all_verified": bool((verdicts == 1).all())})
+        rctx.close()
+
     if rank == 0:
         transforms = 2 * args.polys * args.steps * world
         value = transforms / elapsed
