@@ -39,27 +39,52 @@ def parse():
     ap.add_argument("--no-quotient", action="store_true", help="skip the quotient-polynomial section (SURVEY.md §8(f) rank 2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-polys", type=int, default=8192, help="CPU baseline sample: polynomials transformed fwd+inv on one core (~10 s)")
+    ap.add_argument("--check-polys", type=int, default=64, help="forward outputs compared word for word with the CPU oracle (outside the timed region)")
     return ap.parse_args()
 
 
-def cpu_baseline(sample_polys):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample_polys, gpu_forward_sample, seed_base, commit_check):
     """The oracle (a restatement of the SEAL Harvey NTT the reference calls) timed on ONE host core — the
     reference's execution model is single-threaded.  kind = "port": the reference itself cannot be
-    built here (SEAL absent)."""
+    built here (SEAL absent).  The same leg is the CHECKER of the timed GPU run (outside the timed region): polynomial i
+    is splitmix64(seed_base + i) mod q exactly as on the device, and the oracle's forward outputs of the first
+    len(gpu_forward_sample) polynomials are compared word for word with what the GPU produced."""
     import __graft_entry__ as entry
     orc = entry.load_oracle()
     h = orc.ntt_handle(Q16, N)
     chunk = 64
-    buf = orc.splitmix(0xDEADBEEF, Q16, chunk * N)
     done = 0
-    t0 = time.perf_counter()
+    spent = 0.0
+    matches = True
     while done < sample_polys:
+        buf = np.concatenate([orc.splitmix(seed_base + done + i, Q16, N) for i in range(chunk)])
+        orig = buf.copy() if done == 0 else None
+        t0 = time.perf_counter()
         orc.L.oracle_ntt_forward_batch(h, buf.ctypes.data, chunk)
+        spent += time.perf_counter() - t0
+        if done < len(gpu_forward_sample):
+            take = min(chunk, len(gpu_forward_sample) - done)
+            matches = matches and np.array_equal(buf.reshape(chunk, N)[:take], gpu_forward_sample[done:done + take])
+        t0 = time.perf_counter()
         orc.L.oracle_ntt_inverse_batch(h, buf.ctypes.data, chunk)
+        spent += time.perf_counter() - t0
+        if orig is not None:
+            matches = matches and np.array_equal(buf, orig)
         done += chunk
-    dt = time.perf_counter() - t0
-    single = {"value": 2 * done / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
-              "sample": f"{done} polys x (fwd+inv), n=2^16, q={Q16}, single thread, {dt:.1f} s"}
+    single = {"value": 2 * done / spent, "unit": "NTT/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+              "sample": f"{done} polys x (fwd+inv), n=2^16, q={Q16}, inputs splitmix64(0xDEADBEEF+i), single thread, {spent:.1f} s",
+              "gpu_forward_matches_cpu": bool(matches), "gpu_forward_polys_compared": int(len(gpu_forward_sample))}
     # the same port, one polynomial stream per thread on the box's CPU share for one GPU (16 threads): informational
     import threading
     threads, per_thread = 16, 4
@@ -76,7 +101,25 @@ def cpu_baseline(sample_polys):
     [t.join() for t in ts]
     dt_mt = time.perf_counter() - t0
     single["multithread"] = {"value": 2 * threads * per_thread * chunk / dt_mt, "unit": "NTT/s", "cores": threads}
+    if commit_check is not None:      # config 3 checker: sampled witness vectors of the timed commit batch against the oracle
+        k, a_hat, picks, r_rows, e1_rows, u_rows = commit_check
+        ok = True
+        t0 = time.perf_counter()
+        for j in range(len(picks)):
+            ok = ok and np.array_equal(orc.mlwe_matvec(Q16, N, k, a_hat, r_rows[j], e1_rows[j]), u_rows[j])
+        dt_c = time.perf_counter() - t0
+        single["commit"] = {"value": len(picks) / dt_c, "unit": "commits/s", "cores": 1, "gpu_commit_matches_cpu": bool(ok),
+                            "vectors_compared": [int(x) for x in picks]}
     return single
+
+
+def latest_profile_json(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f)
 
 
 def measured_traffic_per_forward_transform():
@@ -113,8 +156,20 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     gen = torch.Generator(device="cuda")
     gen.manual_seed(0xDEADBEEF + rank)
-    polys = torch.randint(0, Q16, (args.polys, N), dtype=torch.int64, device="cuda", generator=gen)
+    lib = pkg._abi.lib()
+    # polynomial i = splitmix64(0xDEADBEEF + i) mod q, one draw per coefficient (global index i)
+    seed_base = 0xDEADBEEF + rank * args.polys
+    polys = torch.empty((args.polys, N), dtype=torch.int64, device="cuda")
+    assert lib.lsr_fill_splitmix_device(polys.data_ptr(), args.polys, N, seed_base, Q16, stream) == 0
+    torch.cuda.synchronize()
     reference_copy = polys[:8].clone()
+    # checker sample (outside the timed region): forward outputs of the first polynomials, compared with the CPU oracle below
+    n_check = min(args.check_polys, args.polys)
+    ctx.forward_device(polys.data_ptr(), n_check, stream)
+    torch.cuda.synchronize()
+    gpu_forward_sample = polys[:n_check].cpu().numpy().view(np.uint64).copy()
+    ctx.inverse_device(polys.data_ptr(), n_check, stream)
+    torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -156,44 +211,94 @@ def main():
     fwd_rate, inv_rate = args.polys / t_fwd, args.polys / t_inv
 
     extra = {"fwd_ntt_per_s": fwd_rate, "inv_ntt_per_s": inv_rate, "fwd_ms_per_batch": t_fwd * 1e3, "inv_ms_per_batch": t_inv * 1e3,
-             "verified_roundtrip": verified, "arith": "f64-FMA Barrett" if ctx.uses_f64 else "u64 Shoup"}
+             "verified_roundtrip": verified,
+             "arith": ("u64 residues mod q; products by exact FP64-FMA Barrett (q < 2^45, DESIGN.md §4), canonical u64 in and out"
+                       if ctx.uses_f64 else "u64 Harvey/Shoup lazy butterflies")}
+    # the reference's own algorithm (SEAL Harvey butterflies, Shoup products on u64) on the GPU, same array, for comparison
+    lib.lsr_set_arith_mode(1)
+    ctx_u64 = pkg.NttContext(Q16, N, device=local)
+    lib.lsr_set_arith_mode(0)
+    ctx_u64.forward_device(polys.data_ptr(), args.polys, stream)
+    t_fwd_u64 = event_time(lambda: ctx_u64.forward_device(polys.data_ptr(), args.polys, stream), max(3, reps // 2))
+    extra["u64_flavour_fwd_ntt_per_s"] = args.polys / t_fwd_u64
+    extra["u64_flavour_roofline_frac"] = args.polys / t_fwd_u64 * NTT_BYTES / (HBM_PEAK_GBS * 1e9)
+    ctx_u64.close()
 
     # ---- config 3: rank-k Module-LWE matrix–vector commitment u = INTT(A^T NTT(r)) + e1 ----
-    if args.no_commit:
-        del polys
+    commit_check = None
+    commit_roofline = None
+    del polys
     if not args.no_commit:
-        del polys
         torch.cuda.empty_cache()
         k = args.rank
         lctx = pkg.LweContext(pkg.Params(q=Q16, n=N, k=k, sigma=3.19), key_seed=0xC0DE + 1, device=local)
-        r = torch.randint(0, Q16, (args.commits, k, N), dtype=torch.int64, device="cuda", generator=gen)
-        e1 = torch.randint(0, 8, (args.commits, k, N), dtype=torch.int64, device="cuda", generator=gen)   # stand-in blinding residues for timing
+        # r_j uniform from splitmix64(0xC0FFEE + j), e1 from the seeded CDT sampler (sigma = 3.19)
+        first = rank * args.commits
+        r = torch.empty((args.commits, k, N), dtype=torch.int64, device="cuda")
+        assert lib.lsr_fill_splitmix_device(r.data_ptr(), args.commits, k * N, 0xC0FFEE + first, Q16, stream) == 0
+        e1 = torch.empty_like(r)
+        e1_seeds = (np.arange(first + 1, first + args.commits + 1, dtype=np.uint64) * np.uint64(0x9E3779B9))
+        assert lib.lsr_lwe_sample_blinding_device(lctx.handle, e1.data_ptr(), args.commits, e1_seeds.ctypes.data, stream) == 0
         u = torch.empty_like(r)
-        lib = pkg._abi.lib()
+        r_work = torch.empty_like(r)
 
         def commit_step():
-            # the API leaves NTT(r) in r: the next step's witness vectors are those (still uniform residues in [0,q))
-            rc = lib.lsr_mlwe_matvec_batch_device(lctx.handle, r.data_ptr(), e1.data_ptr(), u.data_ptr(), args.commits, None, stream)
+            rc = lib.lsr_mlwe_matvec_batch_device(lctx.handle, r_work.data_ptr(), e1.data_ptr(), u.data_ptr(), args.commits, None, stream)
             assert rc == 0
 
-        for _ in range(max(1, args.warmup // 2)):
-            commit_step()
+        # every step commits to the SAME witness vectors: the entry point may overwrite its r argument with NTT(r), so the
+        # working copy is restored outside the HIP-event bracket of each step
+        def timed_commit_steps(count):
+            evs = []
+            for _ in range(count):
+                r_work.copy_(r)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); commit_step(); b.record()
+                evs.append((a, b))
+            torch.cuda.synchronize()
+            return [a.elapsed_time(b) * 1e-3 for a, b in evs]
+
+        timed_commit_steps(max(1, args.warmup // 2))
         barrier()
-        c0 = time.perf_counter()
         csteps = max(3, args.steps // 2)
-        for _ in range(csteps):
-            commit_step()
-        barrier()
-        c_el = time.perf_counter() - c0
+        c_times = timed_commit_steps(csteps)
+        c_el = float(np.sum(c_times))
         if use_dist:
             t = torch.tensor([c_el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             c_el = float(t.item())
         commit_bytes = 3 * k * N * 8      # read r + read e1 + write u (6 291 456 B at k = 4)
         commits_per_s = world * args.commits * csteps / c_el
+        per_gpu = commits_per_s / world
+        pmc = latest_profile_json("r*_pmc_commit_traffic.json") or {}
+        commit_roofline = {"bound": "hbm", "achieved": per_gpu * commit_bytes / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": per_gpu * commit_bytes / (HBM_PEAK_GBS * 1e9),
+                           "traffic": (pmc.get("bytes_per_commit") or 0) * args.commits or None,
+                           "algorithmic_bytes": commit_bytes * args.commits, "launch_ms": float(np.median(c_times)) * 1e3,
+                           "kernel": pmc.get("kernel", "lsr_mlwe_matvec_batch_device launch sequence (DESIGN.md §5)")}
         extra.update({"commits_per_s": commits_per_s, "commit_rank": k, "commits_per_gpu": args.commits,
-                      "commit_roofline_frac": commits_per_s / world * commit_bytes / (HBM_PEAK_GBS * 1e9)})
+                      "commit_roofline_frac": commit_roofline["frac"], "commit_roofline": commit_roofline})
+        # the same workload with e1 sampled on the device (no e1 array in HBM: 4 194 304 B per commit algorithmic)
+        r_work.copy_(r)
+        assert lib.lsr_mlwe_matvec_batch_device(lctx.handle, r_work.data_ptr(), None, u.data_ptr(), args.commits, e1_seeds.ctypes.data, stream) == 0
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            r_work.copy_(r)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            assert lib.lsr_mlwe_matvec_batch_device(lctx.handle, r_work.data_ptr(), None, u.data_ptr(), args.commits, e1_seeds.ctypes.data, stream) == 0
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        extra["commits_per_s_e1_on_device"] = args.commits / float(np.median(ts))
+        extra["commit_roofline_frac_e1_on_device"] = extra["commits_per_s_e1_on_device"] * 2 * k * N * 8 / (HBM_PEAK_GBS * 1e9)
+        if rank == 0 and not args.no_cpu and world == 1:
+            picks = [0, 127, 128, args.commits - 1]
+            picks = sorted({p for p in picks if 0 <= p < args.commits})
+            tonp = lambda t: t.cpu().numpy().view(np.uint64)
+            commit_check = (k, lctx.public_matrix(), picks, [tonp(r[p]) for p in picks], [tonp(e1[p]) for p in picks], [tonp(u[p]) for p in picks])
         lctx.close()
+        del r, e1, u, r_work
 
     # ---- "next" row: NTT-path quotient polynomials, 4096 instances of m = 4096 constraints ----
     if not args.no_quotient:
@@ -204,7 +309,6 @@ def main():
         ea = torch.randint(-2**63, 2**63 - 1, (qb, qm), dtype=torch.int64, device="cuda", generator=gen)
         eb = torch.randint(-2**63, 2**63 - 1, (qb, qm), dtype=torch.int64, device="cuda", generator=gen)
         ec = torch.empty_like(ea)
-        lib = pkg._abi.lib()
         assert lib.lsr_ntt_mul_pointwise_device(field.handle, ec.data_ptr(), ea.data_ptr(), eb.data_ptr(), qb * qm, stream) == 0   # satisfied: c = a*b
         quot = torch.empty_like(ea)
         qlen = torch.empty(qb, dtype=torch.int32, device="cuda")
@@ -253,7 +357,7 @@ def main():
             "metric": "degree-2^16 NTTs/sec (forward+inverse, batched, device-resident)",
             "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if ctx.uses_f64 else "u64",      # exact integer residues held in FP64 registers (FMA Barrett); I/O is uint64
+            "dtype": "u64",                                 # residues mod q in uint64; the mechanism of the products is in extra.arith
             "data": "synthetic",
             "config": {"workload": "config2: batched forward+inverse negacyclic NTT, n=2^16, 4096 polys/GPU, q=17592182243329 (44-bit)",
                        "polys_per_gpu": args.polys, "ring_degree": N, "modulus": Q16, "parallelism": f"independent batches x{world}, no collectives"},
@@ -266,7 +370,7 @@ def main():
             "extra": extra,
         }
         if not args.no_cpu and world == 1:      # reported at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(args.cpu_polys)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_polys, gpu_forward_sample, seed_base, commit_check)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

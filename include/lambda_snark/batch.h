@@ -105,6 +105,18 @@ int lsr_lwe_verify_opening_batch_flat(const LweContext* ctx, const uint64_t* wor
 int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u,
                                  size_t batch, const uint64_t* seeds, void* stream) LSR_NOEXCEPT;
 
+/* The blinding residues alone: d_e1[batch][k][n] in [0,q), component i of vector j from the seeded CDT stream
+ * (seeds[j], domain 5, i) — exactly what lsr_mlwe_matvec_batch_device samples when d_e1 == NULL.  `seeds` is a HOST
+ * array; the call returns after the samples are complete.  0 / -1. */
+int lsr_lwe_sample_blinding_device(const LweContext* ctx, uint64_t* d_e1, size_t batch, const uint64_t* seeds,
+                                   void* stream) LSR_NOEXCEPT;
+
+/* Synthetic inputs of SURVEY.md section 8(d): d_out[objects][len], element i of object o = the (i+1)-th output of
+ * splitmix64 seeded with seed_base + o, reduced mod q (q = 0: the raw 64-bit word).  Asynchronous on `stream`, launched on
+ * the calling thread's current HIP device.  0 / -1. */
+int lsr_fill_splitmix_device(uint64_t* d_out, size_t objects, size_t len, uint64_t seed_base, uint64_t q,
+                             void* stream) LSR_NOEXCEPT;
+
 /* ---------------- Fiat–Shamir consumer of the commitment words (host, no GPU needed) ---------------- */
 /* The transcript of rust-api/lambda-snark/src/challenge.rs:102-134: SHA3-256 over "LAMBDA-SNARK-R-FS-v1", the
  * public inputs and ALL commitment words (each length-prefixed, little-endian); alpha = LE64(h[0..8]) mod modulus.

@@ -979,6 +979,26 @@ LweCommitment* lwe_linear_combine(const LweContext* ctx, const LweCommitment** c
     }
 }
 
+int lsr_lwe_sample_blinding_device(const LweContext* ctx, uint64_t* d_e1, size_t batch, const uint64_t* seeds, void* stream) noexcept {
+    if (!ctx || !d_e1 || !seeds) return -1;
+    if (batch == 0) return 0;
+    try {
+        lsr::DeviceGuard guard(ctx->device);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        lsr::DeviceBuffer<uint64_t> d_seeds(batch);
+        LSR_HIP(hipMemcpyAsync(d_seeds.ptr, seeds, batch * 8, hipMemcpyHostToDevice, s));
+        lsr::launch_gaussian(lsr::GaussianJob{d_e1, d_seeds.ptr, 0, ctx->k, lsr::kDomE1, ctx->n, batch * ctx->k, ctx->q}, ctx->cdf.ptr, ctx->cdf_entries, s);
+        LSR_HIP(hipStreamSynchronize(s));   // d_seeds dies with this scope
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lsr_lwe_sample_blinding_device: ") + e.what());
+        std::fprintf(stderr, "lambda_snark_core: lsr_lwe_sample_blinding_device failed: %s\n", e.what());
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
 int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, const uint64_t* seeds,
                                  void* stream) noexcept {
     if (!ctx || !d_r || !d_u) return -1;

@@ -1,5 +1,6 @@
 // Discrete-Gaussian / uniform sampling kernels and the sample_gaussian C-ABI
 // (reference: cpp-core/src/utils.cpp:132-146, header cpp-core/include/lambda_snark/utils.h:27).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -57,6 +58,21 @@ __global__ void __launch_bounds__(kSamplerThreads) uniform_kernel(uint64_t* __re
         if ((uint64_t)s < left) dst[s] = __umul64hi(w[s], q);
 }
 
+// out[o][i] = splitmix64_{i}(seed_base + o) mod q (q = 0: the raw word) — the synthetic inputs SURVEY.md §8(d) prescribes for
+// configs 2 and 3 (one draw per coefficient; state after i+1 steps = seed + (i+1) * golden gamma, so every lane is independent)
+__global__ void __launch_bounds__(kSamplerThreads) splitmix_kernel(uint64_t* __restrict__ out, uint64_t objects, uint64_t len, uint64_t seed_base,
+                                                                     uint64_t q) {
+    const uint64_t stride = (uint64_t)gridDim.x * kSamplerThreads;
+    for (uint64_t g = (uint64_t)blockIdx.x * kSamplerThreads + threadIdx.x; g < objects * len; g += stride) {
+        const uint64_t o = g / len, i = g - o * len;
+        uint64_t z = seed_base + o + (i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        out[g] = q ? z % q : z;
+    }
+}
+
 void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream) {
     const uint64_t lanes = ((job.samples + 3) >> 2) * job.objects;
     if (!lanes) return;
@@ -104,6 +120,22 @@ int sample_gaussian(uint64_t* output, size_t len, double sigma) noexcept {
         std::fprintf(stderr, "lambda_snark_core: sample_gaussian failed: %s\n", e.what());
         return -1;
     } catch (...) {
+        return -1;
+    }
+}
+
+int lsr_fill_splitmix_device(uint64_t* d_out, size_t objects, size_t len, uint64_t seed_base, uint64_t q, void* stream) noexcept {
+    if (!d_out) return -1;
+    if (objects == 0 || len == 0) return 0;
+    try {
+        const uint64_t blocks = ((uint64_t)objects * len + lsr::kSamplerThreads - 1) / lsr::kSamplerThreads;
+        const unsigned grid = static_cast<unsigned>(std::min<uint64_t>(blocks, 256ull * 64));
+        hipLaunchKernelGGL(lsr::splitmix_kernel, dim3(grid), dim3(lsr::kSamplerThreads), 0, static_cast<hipStream_t>(stream), d_out, (uint64_t)objects,
+                           (uint64_t)len, seed_base, q);
+        LSR_HIP(hipGetLastError());
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lsr_fill_splitmix_device: ") + e.what());
         return -1;
     }
 }

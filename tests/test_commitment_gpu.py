@@ -331,6 +331,47 @@ def test_config3_matvec_workload(pkg, oracle):
     lctx.close()
 
 
+def test_config3_full_size_device_resident(pkg, oracle):
+    """BASELINE config 3 at FULL size: rank 4, n = 2^16, 1024 witness vectors (2 GiB of r), device-resident, through
+    lsr_mlwe_matvec_batch_device with e1 drawn by the seeded CDT sampler (sigma = 3.19).  r_j uniform from splitmix64
+    seed 0xC0FFEE + j.  Checks: (1) sampled witness vectors — first / last of a register-blocked group
+    of the matrix stage, of a transform chunk (128 vectors = 512 polynomials) and of the batch — bit-exact against
+    oracle.mlwe_matvec with the oracle's own e1; (2) linearity in r over the whole batch, with e1 = 0:
+    L(r_a + r_b) = L(r_a) + L(r_b) for all 512 pairs (a, a + 512)."""
+    import torch
+    q, n, k, batch = 17592182243329, 65536, 4, 1024
+    lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xC0DE)
+    a_hat = lctx.public_matrix()
+    r = np.empty((batch, k, n), dtype=np.uint64)
+    for j in range(batch):
+        r[j] = oracle.splitmix(0xC0FFEE + j, q, k * n).reshape(k, n)
+    seeds = np.arange(1, batch + 1, dtype=np.uint64) * np.uint64(0x9E3779B9)
+    s = torch.cuda.current_stream().cuda_stream
+    d_r = torch.from_numpy(r.view(np.int64)).cuda()
+    d_u = torch.empty_like(d_r)
+    assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), None, d_u.data_ptr(), batch, seeds.ctypes.data, s) == 0
+    torch.cuda.synchronize()
+    picks = [0, 3, 4, 127, 128, 511, 512, 1020, 1023]
+    for j in picks:
+        e1 = np.stack([oracle.sample_gaussian_seeded(n, 3.19, int(seeds[j]), 5, i) for i in range(k)])
+        e1 = np.where(e1 < 0, e1 + q, e1).astype(np.uint64)
+        want = oracle.mlwe_matvec(q, n, k, a_hat, r[j], e1)
+        assert np.array_equal(d_u[j].cpu().numpy().view(np.uint64), want), f"witness vector {j}"
+    # every output is a canonical residue
+    assert int(d_u.max().item()) < q and int(d_u.min().item()) >= 0
+    # linearity with e1 = 0 over the whole batch
+    half = batch // 2
+    d_r.copy_(torch.from_numpy(r.view(np.int64)))
+    d_sum = (d_r[:half] + d_r[half:]) % q
+    zeros = torch.zeros_like(d_r)
+    assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), zeros.data_ptr(), d_u.data_ptr(), batch, None, s) == 0
+    d_us = torch.empty_like(d_sum)
+    assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_sum.data_ptr(), zeros.data_ptr(), d_us.data_ptr(), half, None, s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(d_us, (d_u[:half] + d_u[half:]) % q)
+    lctx.close()
+
+
 def test_verify_opening_batch_matches_single_calls(pkg, oracle):
     """lwe_verify_opening_batch: same 1 / 0 / -1 as one lwe_verify_opening per entry, and as the oracle."""
     q, n, k = 17592186044417, 4096, 2

@@ -39,6 +39,21 @@ def test_survey_check_values(oracle, check_values):
         assert np.array_equal(oracle.ntt_inverse(q, n, f), a)
 
 
+def test_check_values_come_from_the_independent_generator(golden_dir, check_values):
+    """ntt_check_values.json is reproduced by tests/golden/make_ntt_check_values.py — pure Python integers (minimal-psi
+    search, even/odd evaluation, Horner spot checks), nothing shared with oracle/lsr_oracle.c.  Parity stays UNPINNED: the
+    reference holds no forward-NTT vector (cpp-core/tests/test_ntt.cpp:47-81 is a round trip)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_ntt_check_values", os.path.join(golden_dir, "make_ntt_check_values.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    import sys
+    sys.setrecursionlimit(10000)
+    fresh = gen.build()
+    assert fresh["cases"] == check_values["cases"]
+    assert fresh["roots_of_unity"]["table"] == check_values["roots_of_unity"]["table"]
+
+
 def test_roots_of_unity_kat(oracle, check_values):
     r = check_values["roots_of_unity"]
     q = r["q"]
