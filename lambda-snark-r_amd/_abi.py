@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblambda_snark_core.so")
+# LAMBDA_SNARK_CORE_LIB: an experiment build of the same library (csrc/Makefile VARIANT=...), for A/B measurements only
+LIB_PATH = os.environ.get("LAMBDA_SNARK_CORE_LIB") or os.path.join(_HERE, "lib", "liblambda_snark_core.so")
 
 u64 = ctypes.c_uint64
 u32 = ctypes.c_uint32

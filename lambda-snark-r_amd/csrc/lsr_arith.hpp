@@ -71,8 +71,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
+// AUX: cache policy immediate of the buffer instruction; kAuxStream = "nt" (streaming: the line is not kept for re-use).
+// Measured on the two-pass pattern (tools/ubench_move2.hip, profiles/r02_ubench_move2.txt): nt loads + nt stores on the LAST
+// pass of a transform move the data 3 % (n = 2^16) to 10 % (single pass) faster; on a first pass they are slower.
+#ifndef LSR_NT_LAST_PASS
+#define LSR_NT_LAST_PASS 1
+#endif
+constexpr int kAuxStream = LSR_NT_LAST_PASS ? 2 : 0;
+template <int AUX = 0>
 __device__ __forceinline__ uint64_t buf_load64(rsrc_t r, uint32_t lane_bytes, uint32_t const_bytes) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_bytes, (int)const_bytes, 0);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_bytes, (int)const_bytes, AUX);
     return ((uint64_t)v.y << 32) | v.x;
 }
 __device__ __forceinline__ void buf_load128(rsrc_t r, uint32_t lane_bytes, uint32_t const_bytes, uint64_t& a, uint64_t& b) {
@@ -80,11 +88,12 @@ __device__ __forceinline__ void buf_load128(rsrc_t r, uint32_t lane_bytes, uint3
     a = ((uint64_t)v.y << 32) | v.x;
     b = ((uint64_t)v.w << 32) | v.z;
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store64(rsrc_t r, uint32_t lane_bytes, uint32_t const_bytes, uint64_t x) {
     u32x2 v;
     v.x = (uint32_t)x;
     v.y = (uint32_t)(x >> 32);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)lane_bytes, (int)const_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)lane_bytes, (int)const_bytes, AUX);
 }
 
 struct ArithF64 {

@@ -21,6 +21,7 @@
 #include "lambda_snark/batch.h"
 #include "lambda_snark/commitment.h"
 #include "lsr_arith.hpp"
+#include "lsr_commit_fused.hpp"
 #include "lsr_runtime.hpp"
 #include "lsr_sampler.hpp"
 
@@ -258,6 +259,13 @@ struct LweContext {
     // pinned host staging for the gather of a batch (two bulk D2H copies instead of two per commitment)
     mutable uint64_t* host_stage = nullptr;
     mutable size_t host_stage_words = 0;
+    // fused matrix–vector pipeline (lsr_commit_fused.hpp): lane-major copy of A_hat, per-stream chunk workspaces, side streams
+    static constexpr int kMaxSide = 4;
+    lsr::DeviceBuffer<double> a_perm;
+    mutable lsr::DeviceBuffer<uint64_t> ws_mid;
+    mutable hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
+    mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
+    mutable int n_side = 0;
 };
 
 namespace lsr {
@@ -320,6 +328,11 @@ static void ensure_workspace(const LweContext& c, size_t batch) {
     c.ws_batch = batch;
 }
 
+// the fused pipeline exists for the FP64 flavour, two-pass degrees whose low pass is a full 4096-residue tile, ranks <= 4
+static bool fused_eligible(const LweContext& c) {
+    return c.ntt->use_f64 && (c.logn == 16 || c.logn == 17) && c.k >= 1 && c.k <= 4;
+}
+
 static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_seed, int device) {
     if (!params) return nullptr;                                   // commitment.cpp:103
     uint32_t k = params->module_rank ? params->module_rank : 1;
@@ -366,6 +379,11 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
         launch_ntt(*c->ntt, e_hat.ptr, k, false, s);
         // b_hat[i] = sum_j A_hat[i][j] s_hat[j] + e_hat[i]
         matvec_square(*c, c->b_hat.ptr, c->a_hat.ptr, c->s_hat.ptr, e_hat.ptr, false, 1, s);
+        if (fused_eligible(*c)) {
+            c->a_perm.allocate((size_t)k * kn);
+            hipLaunchKernelGGL(f8_permute_matrix_kernel, dim3(grid_for((uint64_t)k * kn)), dim3(256), 0, s, c->a_perm.ptr, c->a_hat.ptr, k, c->logn);
+            LSR_HIP(hipGetLastError());
+        }
         LSR_HIP(hipStreamSynchronize(s));
     } catch (const std::exception& e) {
         set_last_error(std::string("lwe_context_create: ") + e.what());
@@ -387,6 +405,12 @@ static void destroy_lwe_context(LweContext* c) {
         c->a_hat.release(); c->s_hat.release(); c->b_hat.release(); c->cdf.release();
         c->ws_r.release(); c->ws_e1.release(); c->ws_e2.release(); c->ws_u.release(); c->ws_v.release();
         c->ws_dm.release(); c->ws_seeds.release(); c->ws_flag.release();
+        c->a_perm.release(); c->ws_mid.release();
+        for (int i = 0; i < c->n_side; ++i) {
+            if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+            if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+        }
+        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
         if (c->host_stage) (void)hipHostFree(c->host_stage);
     } catch (...) {
     }
@@ -394,9 +418,76 @@ static void destroy_lwe_context(LweContext* c) {
     delete c;
 }
 
-// u = INTT(A_hat^T NTT(r)) + e1 on device-resident [batch][k][n] arrays (r is overwritten by NTT(r))
-static void mlwe_matvec_device(const LweContext& c, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s) {
+static int env_int(const char* name, int fallback, int lo, int hi) {
+    if (const char* e = std::getenv(name)) {
+        const long v = std::atol(e);
+        if (v >= lo && v <= hi) return static_cast<int>(v);
+    }
+    return fallback;
+}
+
+template <int K>
+static void launch_mid(const LweContext& c, const uint64_t* ws, uint64_t* d_u, size_t vectors, hipStream_t s) {
+    const unsigned grid = static_cast<unsigned>(vectors << (c.logn - 12));
+    // experiment knob: unused dynamic LDS that lowers the kernel's residency (e.g. 16384 -> one workgroup per CU), leaving
+    // registers and wave slots for the memory-bound outer rounds of neighbouring chunks on other streams
+    const unsigned pad = static_cast<unsigned>(env_int("LAMBDA_SNARK_COMMIT_MID_LDS_PAD", 0, 0, 90000));
+    hipLaunchKernelGGL((mlwe_mid_fused8<K>), dim3(grid), dim3(kF8Threads), pad, s, ws, d_u, c.a_perm.ptr, (uint32_t)vectors, c.ntt->mod, c.ntt->fwd_f64.ptr,
+                       c.ntt->inv_f64.ptr);
+    LSR_HIP(hipGetLastError());
+}
+
+// Fused pipeline (caller holds c.mutex): per chunk of witness vectors
+//   top forward round r -> workspace | 12 forward stages x k, A_hat^T product, 12 inverse stages x k -> u | top inverse round (+ e1)
+// with the chunks dealt round-robin to side streams, so that the FP64-bound middle kernel of one chunk runs beside the
+// HBM-bound outer rounds of its neighbours.  d_r is only read.
+static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s) {
     const uint32_t k = c.k;
+    const size_t vec_words = (size_t)k << c.logn;
+    const int want = env_int("LAMBDA_SNARK_COMMIT_STREAMS", 3, 1, LweContext::kMaxSide);
+    const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_CHUNK_MIB", 128, 1, 4096);
+    const size_t chunk = std::max<size_t>(1, (chunk_mib << 20) / (vec_words * 8));
+    const int streams = static_cast<int>(std::min<size_t>((size_t)want, (batch + chunk - 1) / chunk));
+    while (c.n_side < streams) {
+        LSR_HIP(hipStreamCreateWithFlags(&c.side[c.n_side], hipStreamNonBlocking));
+        LSR_HIP(hipEventCreateWithFlags(&c.ev_join[c.n_side], hipEventDisableTiming));
+        ++c.n_side;
+    }
+    if (!c.ev_fork) LSR_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+    const size_t slot_words = std::min(chunk, batch) * vec_words;
+    if (c.ws_mid.count < slot_words * streams) c.ws_mid.allocate(slot_words * streams);
+    LSR_HIP(hipEventRecord(c.ev_fork, s));
+    for (int i = 0; i < streams; ++i) LSR_HIP(hipStreamWaitEvent(c.side[i], c.ev_fork, 0));
+    size_t index = 0;
+    for (size_t first = 0; first < batch; first += chunk, ++index) {
+        const size_t now = std::min(chunk, batch - first);
+        hipStream_t st = c.side[index % streams];
+        uint64_t* const ws = c.ws_mid.ptr + (index % streams) * slot_words;
+        launch_top_round_forward(*c.ntt, ws, d_r + first * vec_words, now * k, st);
+        switch (k) {
+            case 1: launch_mid<1>(c, ws, d_u + first * vec_words, now, st); break;
+            case 2: launch_mid<2>(c, ws, d_u + first * vec_words, now, st); break;
+            case 3: launch_mid<3>(c, ws, d_u + first * vec_words, now, st); break;
+            default: launch_mid<4>(c, ws, d_u + first * vec_words, now, st); break;
+        }
+        launch_top_round_inverse(*c.ntt, d_u + first * vec_words, now * k, st, d_e1 ? d_e1 + first * vec_words : nullptr);
+    }
+    for (int i = 0; i < streams; ++i) {
+        LSR_HIP(hipEventRecord(c.ev_join[i], c.side[i]));
+        LSR_HIP(hipStreamWaitEvent(s, c.ev_join[i], 0));
+    }
+}
+
+// u = INTT(A_hat^T NTT(r)) + e1 on device-resident [batch][k][n] arrays.  Unfused form: r is overwritten by NTT(r), which
+// commit_compute then reuses for the scalar component; `allow_fused` callers do not need NTT(r) and leave r untouched when
+// the context qualifies for the fused pipeline (they hold c.mutex).
+static void mlwe_matvec_device(const LweContext& c, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s,
+                               bool allow_fused = false) {
+    const uint32_t k = c.k;
+    if (allow_fused && c.a_perm.ptr && env_int("LAMBDA_SNARK_COMMIT_FUSED", 1, 0, 1)) {
+        mlwe_matvec_fused(c, d_r, d_e1, d_u, batch, s);
+        return;
+    }
     launch_ntt(*c.ntt, d_r, batch * k, false, s);
     // u[j][col] = sum_i A_hat[i][col] r_hat[j][i]
     matvec_square(c, d_u, c.a_hat.ptr, d_r, nullptr, true, batch, s);
@@ -1007,17 +1098,17 @@ int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uin
     try {
         lsr::DeviceGuard guard(ctx->device);
         hipStream_t s = static_cast<hipStream_t>(stream);
+        std::lock_guard<std::mutex> lock(ctx->mutex);
         if (d_e1) {
-            lsr::mlwe_matvec_device(*ctx, d_r, d_e1, d_u, batch, s);
+            lsr::mlwe_matvec_device(*ctx, d_r, d_e1, d_u, batch, s, true);
             return 0;
         }
         // e1 sampled on the device from the per-commit seeds (domain 5), then added
-        std::lock_guard<std::mutex> lock(ctx->mutex);
         lsr::ensure_workspace(*ctx, batch);
         LSR_HIP(hipMemcpyAsync(ctx->ws_seeds.ptr, seeds, batch * 8, hipMemcpyHostToDevice, s));
         lsr::launch_gaussian(lsr::GaussianJob{ctx->ws_e1.ptr, ctx->ws_seeds.ptr, 0, ctx->k, lsr::kDomE1, ctx->n, batch * ctx->k, ctx->q}, ctx->cdf.ptr,
                              ctx->cdf_entries, s);
-        lsr::mlwe_matvec_device(*ctx, d_r, ctx->ws_e1.ptr, d_u, batch, s);
+        lsr::mlwe_matvec_device(*ctx, d_r, ctx->ws_e1.ptr, d_u, batch, s, true);
         LSR_HIP(hipStreamSynchronize(s));   // seeds is a host array the caller may reuse
         return 0;
     } catch (const std::exception& e) {

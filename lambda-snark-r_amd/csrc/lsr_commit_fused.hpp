@@ -1,0 +1,274 @@
+// Fused middle stage of the Module-LWE matrix–vector product u = INTT(A_hat^T NTT(r)) + e1 for n = 2^16 / 2^17
+// ("fused NTT -> MAC -> INTT pipeline"; contract cpp-core/include/lambda_snark/commitment.h:43-52).
+//
+// Pipeline per chunk of witness vectors (lsr_commit.hip::mlwe_matvec_fused):
+//     ntt_strided_round (top index bits, r -> workspace, raw f64)                      4 + 4 polynomial passes per vector
+//     mlwe_mid_fused8   (this file: 12 forward stages x K, A_hat^T product, 12 inverse stages x K)      4 + 4
+//     ntt_strided_round (top bits of the inverse, n^-1, + e1, canonical store)         4 + 4 + 4
+// i.e. 28 polynomial passes per rank-4 commitment instead of 44: NTT(r) and A_hat^T NTT(r) never reach HBM.
+//
+// One 512-lane workgroup owns the same 4096-residue tile of the K polynomials of one witness vector.  A lane holds 8
+// residues (radix-8 rounds: index bits [9,12), [6,9), [3,6), [0,3)), so the K accumulators of the product cost 8 K doubles
+// per lane and the kernel stays at 128 VGPRs = 4 waves per SIMD = two workgroups per CU (the round-1 experiment with 16
+// residues per lane sat at 256 VGPRs + spills, 2 waves per SIMD: profiles/r01_fused_commit_experiment.txt).  The K
+// polynomials go through the tile one after the other; only the accumulators persist.
+//
+// LDS (69 120 B per workgroup):
+//   * the tile, 4608 doubles, at slot(idx) = sum_j W_j idx_j with W = {1,2,4,8,16,32,72,144,289,578,1156,2304}: a weighted
+//     sum of index bits is additive over disjoint bit fields (lane part + immediate register offset), and the weights are
+//     chosen so that, with the lane maps below, the 32 lanes of a ds_read_b64 group hit 32 different 8-byte banks and the 16
+//     lanes of a ds_write_b64 group 16 different ones in every round (tools/experiments/sim_fused8.py checks both and the
+//     whole butterfly network against the plain stage loop on the CPU);
+//   * twiddles: rounds [9,12) and [6,9) need workgroup- resp. wavefront-uniform multipliers (scalar loads); round [3,6) reads
+//     a 448-entry image of the three sub-tables in natural order; round [0,3) multipliers are private to a lane and parked
+//     thread-major (7 x 512 doubles) instead of occupying 14 VGPRs.  The image is rebuilt for the inverse direction.
+// The matrix is read in a lane-major permuted copy (16 B per lane, coalesced): a_perm[tile][i][c][kp][lane][2].
+// FP64 flavour only (q < 2^45); other moduli, ranks > 4 and other degrees use the unfused kernels.
+#pragma once
+
+#include "lsr_ntt_kernels.hpp"
+
+#ifndef LSR_F8_TOUCH
+#define LSR_F8_TOUCH 1
+#endif
+
+namespace lsr {
+
+constexpr int kF8Threads = 512;
+constexpr int kF8Regs = 8;
+constexpr uint32_t kF8TileWords = 4608;
+constexpr uint32_t kF8TwShared = 448;              // sub-tables of index bits 5, 4, 3: 64 + 128 + 256 entries
+constexpr uint32_t kF8TwPrivate = 7 * kF8Threads;  // index bits 2, 1, 0: 7 multipliers per lane
+
+__host__ __device__ constexpr uint32_t f8_slot(uint32_t idx) {
+    return (idx & 63u) + 72u * ((idx >> 6) & 1u) + 144u * ((idx >> 7) & 1u) + 289u * ((idx >> 8) & 1u) + 578u * ((idx >> 9) & 1u) +
+           1156u * ((idx >> 10) & 1u) + 2304u * ((idx >> 11) & 1u);
+}
+// low index bit of the register field of round R (R = 0 is the first forward round)
+__host__ __device__ constexpr int f8_lo(int round) { return 9 - 3 * round; }
+// tile index of register 0 of lane t in round R
+template <int R>
+__host__ __device__ constexpr uint32_t f8_base(uint32_t t) {
+    if (R == 0) return t;
+    if (R == 1) return (t & 63u) | ((t >> 6) << 9);
+    if (R == 2) return (t & 7u) | ((t >> 3) << 6);
+    return (((t >> 3) & 31u) << 3) | ((t & 7u) << 8) | ((t >> 8) << 11);
+}
+
+// multipliers of one round in the order [j = 2][j = 1: u = 0, 1][j = 0: u = 0..3] (j = register bit); `tw(s)` yields the
+// s-th of them at its point of use, so that multipliers parked in LDS are not all live at once
+template <class TW>
+__device__ __forceinline__ void f8_forward_round(double (&v)[kF8Regs], TW&& tw, const ModParams& p) {
+    {
+        const double w = tw(0);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) ArithF64::ct(v[l], v[l + 4], w, p);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const double w = tw(1 + u);
+#pragma unroll
+        for (int l = 0; l < 2; ++l) ArithF64::ct(v[4 * u + l], v[4 * u + l + 2], w, p);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ArithF64::ct(v[2 * u], v[2 * u + 1], tw(3 + u), p);
+}
+// RECENTRE: bring the outputs back to |v| <= q/2.  A round multiplies the bound of the sum outputs by 8, and every
+// product input must stay below 2^50 > 32 q: from q/2 two rounds may pass (4 q, 32 q) before a re-centring.
+template <bool RECENTRE, class TW>
+__device__ __forceinline__ void f8_inverse_round(double (&v)[kF8Regs], TW&& tw, const ModParams& p) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ArithF64::gs(v[2 * u], v[2 * u + 1], tw(3 + u), p);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const double w = tw(1 + u);
+#pragma unroll
+        for (int l = 0; l < 2; ++l) ArithF64::gs(v[4 * u + l], v[4 * u + l + 2], w, p);
+    }
+    {
+        const double w = tw(0);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) ArithF64::gs(v[l], v[l + 4], w, p);
+    }
+    if constexpr (RECENTRE) {
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) v[k] = recentre_f64(v[k], p.qd, p.inv_qd);
+    }
+}
+
+// table indices of the multipliers of a round whose register-0 position inside the polynomial is pos0
+template <int R>
+__device__ __forceinline__ void f8_uniform_twiddles(double (&w)[7], const double* __restrict__ table, uint32_t pos0, int logn) {
+    constexpr int LO = f8_lo(R);
+#pragma unroll
+    for (int j = 2; j >= 0; --j) {
+        const int b = LO + j;
+        const uint32_t first = (1u << (logn - 1 - b)) + (pos0 >> (b + 1));
+#pragma unroll
+        for (int u = 0; u < (1 << (2 - j)); ++u) w[((1 << (2 - j)) - 1) + u] = table[first + u];
+    }
+}
+
+// (re)build the LDS twiddle image for one direction; the caller separates it from its readers with barriers
+__device__ __forceinline__ void f8_fill_twiddles(double* __restrict__ tw_lds, const double* __restrict__ table, uint32_t tile_pos, int logn, uint32_t t) {
+    if (t < kF8TwShared) {
+        const int b = t < 64 ? 5 : (t < 192 ? 4 : 3);
+        const uint32_t e = t < 64 ? t : (t < 192 ? t - 64 : t - 192);
+        tw_lds[t] = table[(1u << (logn - 1 - b)) + (tile_pos >> (b + 1)) + e];
+    }
+    const uint32_t pos0 = tile_pos + f8_base<3>(t);
+    double mine[7];
+    f8_uniform_twiddles<3>(mine, table, pos0, logn);
+#pragma unroll
+    for (int s = 0; s < 7; ++s) tw_lds[kF8TwShared + s * kF8Threads + t] = mine[s];
+}
+
+// a_perm[tile][i][c][kp][lane][e] = (double) a_hat[i][c][tile * 4096 + f8_base<3>(lane) + 2 kp + e]
+static __global__ void __launch_bounds__(256) f8_permute_matrix_kernel(double* __restrict__ a_perm, const uint64_t* __restrict__ a_hat, uint32_t k,
+                                                                         int logn) {
+    const uint64_t total = (uint64_t)k * k << logn;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
+        const uint32_t e = g & 1u, lane = (g >> 1) & 511u, kp = (g >> 10) & 3u;
+        const uint64_t rest = g >> 12;                       // (tile * k + i) * k + c
+        const uint32_t c = rest % k, i = (rest / k) % k;
+        const uint64_t tile = rest / ((uint64_t)k * k);
+        const uint64_t x = (tile << 12) + f8_base<3>(lane) + 2 * kp + e;
+        a_perm[g] = f64_from_u52(a_hat[(((uint64_t)i * k + c) << logn) + x]);
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t* __restrict__ rws, uint64_t* __restrict__ u,
+                                                                  const double* __restrict__ a_perm, uint32_t vectors, ModParams p,
+                                                                  const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
+    __shared__ double tile_lds[kF8TileWords];
+    __shared__ double tw_lds[kF8TwShared + kF8TwPrivate];
+    const uint32_t t = threadIdx.x;
+    // (witness vector j, tile).  Workgroups b and b + 8 share an XCD under the observed round-robin placement (speed only):
+    // an XCD then sees 2 of the >= 16 tile positions of A_hat, which stay in its L2.
+    const int tp_log = p.logn - 12;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t rest = blk >> 3;
+    const uint32_t tile = (blk & 7u) | ((rest & ((1u << (tp_log - 3)) - 1u)) << 3);
+    const uint32_t j = rest >> (tp_log - 3);
+    if (j >= vectors) return;
+    const uint32_t tile_pos = tile << 12;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(t & ~63u);
+    // per-round LDS addresses of register 0 (doubles)
+    double* const row0 = tile_lds + f8_slot(f8_base<0>(t));
+    double* const row1 = tile_lds + f8_slot(f8_base<1>(t));
+    double* const row2 = tile_lds + f8_slot(f8_base<2>(t));
+    double* const row3 = tile_lds + f8_slot(f8_base<3>(t));
+    const double* const tw2 = tw_lds;                                   // natural-order sub-tables of bits 5, 4, 3
+    const double* const tw3 = tw_lds + kF8TwShared + t;                 // this lane's 7 multipliers, stride 512
+    const uint32_t e5 = f8_base<2>(t) >> 6, e4 = f8_base<2>(t) >> 5, e3 = f8_base<2>(t) >> 4;
+
+    double acc[K][kF8Regs];
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) acc[c][k] = 0.0;
+
+    f8_fill_twiddles(tw_lds, fwd_tw, tile_pos, p.logn, t);
+    double w0[7], w1[7];
+    f8_uniform_twiddles<0>(w0, fwd_tw, tile_pos, p.logn);
+    f8_uniform_twiddles<1>(w1, fwd_tw, tile_pos + f8_base<1>(wave0), p.logn);
+    __syncthreads();
+
+    // ---- forward: the K polynomials of the vector, one after the other ---------------------------------------------------
+    const auto tw_r0 = [&](int s_) { return w0[s_]; };
+    const auto tw_r1 = [&](int s_) { return w1[s_]; };
+    const auto tw_r2 = [&](int s_) { return s_ == 0 ? tw2[e5] : (s_ < 3 ? tw2[64 + e4 + (s_ - 1)] : tw2[192 + e3 + (s_ - 3)]); };
+    const auto tw_r3 = [&](int s_) { return tw3[s_ * kF8Threads]; };
+#pragma unroll 1
+    for (int i = 0; i < K; ++i) {
+        double v[kF8Regs];
+        {
+            const rsrc_t src = make_rsrc(rws + ((((size_t)j * K + i) << p.logn) + tile_pos), 4096u * 8u);
+#pragma unroll
+            for (int k = 0; k < kF8Regs; ++k) v[k] = __longlong_as_double((long long)buf_load64(src, t * 8u, (uint32_t)k * 4096u));
+        }
+        f8_forward_round(v, tw_r0, p);
+        if (i > 0) __syncthreads();                      // the previous polynomial's last LDS reads are done
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) row0[f8_slot((uint32_t)k << 9)] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) v[k] = row1[f8_slot((uint32_t)k << 6)];
+#if LSR_F8_TOUCH
+        // Pull the next polynomial's tile towards this XCD's L2 three rounds ahead of its use: one dword per 128-byte line
+        // (a real prefetch into registers would need 16 more VGPRs than the 128 that two workgroups per CU allow).
+        uint32_t touch = 0;
+        if (i + 1 < K && t < 256) {
+            const rsrc_t nxt = make_rsrc(rws + ((((size_t)j * K + i + 1) << p.logn) + tile_pos), 4096u * 8u);
+            touch = __builtin_amdgcn_raw_buffer_load_b32(nxt, (int)(t * 128u), 0, 0);
+        }
+#endif
+        f8_forward_round(v, tw_r1, p);
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) row1[f8_slot((uint32_t)k << 6)] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) v[k] = row2[f8_slot((uint32_t)k << 3)];
+        f8_forward_round(v, tw_r2, p);
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) row2[f8_slot((uint32_t)k << 3)] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) v[k] = row3[k];
+        f8_forward_round(v, tw_r3, p);
+        // acc[c] += A_hat[i][c] o r_hat_i on this lane's 8 positions
+        const double* const mat = a_perm + ((((size_t)tile * K + i) * K) << 12) + (size_t)t * 2;
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+                const double2 a = *reinterpret_cast<const double2*>(mat + (((size_t)c * 4 + kp) << 10));
+                acc[c][2 * kp] += mulmod_f64(v[2 * kp], a.x, p.qd, p.inv_qd);
+                acc[c][2 * kp + 1] += mulmod_f64(v[2 * kp + 1], a.y, p.qd, p.inv_qd);
+            }
+        }
+#if LSR_F8_TOUCH
+        asm volatile("" ::"v"(touch));
+#endif
+    }
+
+    // ---- inverse: each output component through the tile ------------------------------------------------------------------
+    __syncthreads();                                     // every lane is done with the forward twiddle image
+    f8_fill_twiddles(tw_lds, inv_tw, tile_pos, p.logn, t);
+    f8_uniform_twiddles<0>(w0, inv_tw, tile_pos, p.logn);
+    f8_uniform_twiddles<1>(w1, inv_tw, tile_pos + f8_base<1>(wave0), p.logn);
+    __syncthreads();
+    static_for<0, K>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        double x[kF8Regs];
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) x[k] = recentre_f64(acc[c][k], p.qd, p.inv_qd);
+        f8_inverse_round<false>(x, tw_r3, p);             // |x| <= 4 q
+        if constexpr (c > 0) __syncthreads();            // the previous component's last LDS reads are done
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) row3[k] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) x[k] = row2[f8_slot((uint32_t)k << 3)];
+        f8_inverse_round<true>(x, tw_r2, p);              // 32 q -> q/2
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) row2[f8_slot((uint32_t)k << 3)] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) x[k] = row1[f8_slot((uint32_t)k << 6)];
+        f8_inverse_round<false>(x, tw_r1, p);             // 4 q
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) row1[f8_slot((uint32_t)k << 6)] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) x[k] = row0[f8_slot((uint32_t)k << 9)];
+        f8_inverse_round<true>(x, tw_r0, p);              // 32 q -> q/2: what the strided round expects
+        const rsrc_t dst = make_rsrc(u + ((((size_t)j * K + c) << p.logn) + tile_pos), 4096u * 8u);
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) buf_store64(dst, t * 8u, (uint32_t)k * 4096u, (uint64_t)__double_as_longlong(x[k]));
+    });
+}
+
+}  // namespace lsr

@@ -349,6 +349,21 @@ void launch_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hi
     LSR_HIP(hipGetLastError());
 }
 
+// The strided (top index bits) round of an n > 4096 transform on its own: the outer passes of the fused commitment
+// pipeline (lsr_commit.hip), whose middle stage replaces the tile kernels.  FP64 flavour.
+void launch_top_round_forward(const NttContext& c, uint64_t* dst, const uint64_t* src, size_t polys, hipStream_t s) {
+    if (!c.use_f64 || c.logn <= kTileLog) throw std::runtime_error("top-round launch: FP64 flavour, n > 4096 only");
+    const int r_top = std::max(c.logn - kTileLog, 4);
+    strided<ArithF64, false, false, true>(c, dst, polys << c.logn, c.logn - r_top, r_top, s, src);
+    LSR_HIP(hipGetLastError());
+}
+void launch_top_round_inverse(const NttContext& c, uint64_t* data, size_t polys, hipStream_t s, const uint64_t* add) {
+    if (!c.use_f64 || c.logn <= kTileLog) throw std::runtime_error("top-round launch: FP64 flavour, n > 4096 only");
+    const int r_top = std::max(c.logn - kTileLog, 4);
+    strided<ArithF64, true, true, false>(c, data, polys << c.logn, c.logn - r_top, r_top, s, add);
+    LSR_HIP(hipGetLastError());
+}
+
 void launch_pointwise(const NttContext& c, uint64_t* out, const uint64_t* a, const uint64_t* b, size_t count, hipStream_t s) {
     if (!count) return;
     const size_t want = (count + kThreads - 1) / kThreads;

@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restric
         const uint32_t base = lane_base<LO, R>(t);
         uint64_t raw[kRegs];
 #pragma unroll
-        for (int k = 0; k < kRegs; ++k) raw[k] = buf_load64(from, base * 8u, reg_offset<LO, R>(k) * 8u);
+        for (int k = 0; k < kRegs; ++k) raw[k] = buf_load64<RAW_OUT ? 0 : kAuxStream>(from, base * 8u, reg_offset<LO, R>(k) * 8u);
         load_round_twiddles<A, LO, R, false, false>(w[0], base, block_pos, nmask, p.logn, table);
 #pragma unroll
         for (int k = 0; k < kRegs; ++k) v[k] = RAW_IN ? elem_from_bits<A>(raw[k]) : A::load(raw[k], p);
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restric
 #pragma unroll
     for (int k = 0; k < kRegs; ++k) {
         const uint64_t bits = col[lds_slot((uint32_t)k * kThreads)];
-        buf_store64(tile, t * 8u, (uint32_t)k * kThreads * 8u, RAW_OUT ? bits : A::store_canonical(elem_from_bits<A>(bits), p));
+        buf_store64<RAW_OUT ? 0 : kAuxStream>(tile, t * 8u, (uint32_t)k * kThreads * 8u, RAW_OUT ? bits : A::store_canonical(elem_from_bits<A>(bits), p));
     }
 }
 
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
     {   // coalesced read-in to LDS (raw element bits); the first round's twiddles ride along
         uint64_t raw[kRegs];
 #pragma unroll
-        for (int k = 0; k < kRegs; ++k) raw[k] = buf_load64(tile, t * 8u, (uint32_t)k * kThreads * 8u);
+        for (int k = 0; k < kRegs; ++k) raw[k] = buf_load64<RAW_OUT ? 0 : kAuxStream>(tile, t * 8u, (uint32_t)k * kThreads * 8u);
         constexpr int J = NR - 1;
         constexpr int LO = TileRound<LT, J>::LO, R = TileRound<LT, J>::R;
         load_round_twiddles<A, LO, R, true, (NR == 1) && !RAW_OUT>(w[0], lane_base<LO, R>(t), block_pos, nmask, p.logn, table);
@@ -307,11 +307,11 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
             if (!RAW_OUT && add != nullptr) {
 #pragma unroll
                 for (int k = 0; k < kRegs; ++k)
-                    buf_store64(tile, base * 8u, reg_offset<LO, R>(k) * 8u, A::store_reduced_plus(v[k], blind[k], p));
+                    buf_store64<kAuxStream>(tile, base * 8u, reg_offset<LO, R>(k) * 8u, A::store_reduced_plus(v[k], blind[k], p));
             } else {
 #pragma unroll
                 for (int k = 0; k < kRegs; ++k)
-                    buf_store64(tile, base * 8u, reg_offset<LO, R>(k) * 8u, RAW_OUT ? elem_bits<A>(v[k]) : A::store_reduced(v[k], p));
+                    buf_store64<RAW_OUT ? 0 : kAuxStream>(tile, base * 8u, reg_offset<LO, R>(k) * 8u, RAW_OUT ? elem_bits<A>(v[k]) : A::store_reduced(v[k], p));
             }
         } else {
 #pragma unroll
@@ -342,7 +342,8 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
     const uint64_t* const from = (!INVERSE && add != nullptr) ? add : data;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const uint64_t raw = from[idx0 + ((size_t)k << lo)];
+        constexpr bool kStream = LSR_NT_LAST_PASS && INVERSE && !RAW_OUT;   // last pass of an inverse transform
+        const uint64_t raw = kStream ? __builtin_nontemporal_load(from + idx0 + ((size_t)k << lo)) : from[idx0 + ((size_t)k << lo)];
         v[k] = RAW_IN ? elem_from_bits<A>(raw) : A::load(raw, p);
     }
     if constexpr (ADD) {   // the blinding residues travel with the operands, not behind the arithmetic
@@ -394,7 +395,8 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
         if (RAW_OUT) out = elem_bits<A>(v[k]);
         else if constexpr (ADD) out = A::store_reduced_plus(v[k], extra[k], p);
         else out = INVERSE ? A::store_reduced(v[k], p) : A::store_canonical(v[k], p);
-        data[gi] = out;
+        if constexpr (LSR_NT_LAST_PASS && INVERSE && !RAW_OUT) __builtin_nontemporal_store(out, data + gi);
+        else data[gi] = out;
     }
 }
 

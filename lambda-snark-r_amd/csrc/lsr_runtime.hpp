@@ -112,6 +112,10 @@ void destroy_ntt_context(NttContext* ctx);
 void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inverse, hipStream_t stream,
                 const uint64_t* add_on_inverse = nullptr, const uint64_t* pre_mul_on_inverse = nullptr,
                 const uint64_t* forward_source = nullptr);
+// only the strided top-bits round of an n > 4096 FP64-flavour transform: forward reads canonical `src`, writes raw elements
+// to `dst` (may alias); inverse turns raw elements into canonical residues (+ optional canonical `add`), in place
+void launch_top_round_forward(const NttContext& ctx, uint64_t* d_dst, const uint64_t* d_src, size_t polys, hipStream_t stream);
+void launch_top_round_inverse(const NttContext& ctx, uint64_t* d_data, size_t polys, hipStream_t stream, const uint64_t* add);
 void launch_pointwise(const NttContext& ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t count,
                       hipStream_t stream);
 // out[b][i] = in[b][bitrev_logn(i)] (out != in)

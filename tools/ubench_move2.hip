@@ -1,0 +1,97 @@
+// Microbenchmark (round 2): pure data movement of the two passes of the n = 2^16 transform, in place, per access variant —
+// 8 vs 16 bytes per lane, default vs non-temporal loads / stores — with a little arithmetic so nothing is optimised away.
+// Answers VERDICT r1 "What's weak" #4: do b128 accesses or a streaming cache policy move the two-pass floor (1.29 ms)?
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench_move2.hip -o tools/bin/ubench_move2
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <algorithm>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+template <int W, bool NT> __device__ __forceinline__ void ld(const uint64_t* p, uint64_t (&v)[W]) {
+    if constexpr (W == 1) { v[0] = NT ? __builtin_nontemporal_load(p) : *p; }
+    else { const u64x2 x = NT ? __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(p)) : *reinterpret_cast<const u64x2*>(p); v[0] = x.x; v[1] = x.y; }
+}
+template <int W, bool NT> __device__ __forceinline__ void st(uint64_t* p, const uint64_t (&v)[W]) {
+    if constexpr (W == 1) { if (NT) __builtin_nontemporal_store(v[0], p); else *p = v[0]; }
+    else { u64x2 x; x.x = v[0]; x.y = v[1]; if (NT) __builtin_nontemporal_store(x, reinterpret_cast<u64x2*>(p)); else *reinterpret_cast<u64x2*>(p) = x; }
+}
+
+// pass 1: 16 rows 4096 apart (the strided top-bits round); a lane owns W adjacent columns
+template <int W, bool NTL, bool NTS>
+__global__ void __launch_bounds__(256) pass1(uint64_t* __restrict__ d, size_t total) {
+    const size_t g = ((size_t)blockIdx.x * 256 + threadIdx.x) * W;
+    if (g >= total / 16) return;
+    const size_t idx0 = ((g >> 12) << 16) | (g & 4095);
+    uint64_t v[16][W];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ld<W, NTL>(d + idx0 + ((size_t)k << 12), v[k]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int w = 0; w < W; ++w) v[k][w] = v[k][w] * 3 + v[(k + 1) & 15][w];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st<W, NTS>(d + idx0 + ((size_t)k << 12), v[k]);
+}
+// pass 2: contiguous 4096-element tiles (256 lanes x 16 residues), a lane owns W adjacent residues per row of 256 W
+template <int W, bool NTL, bool NTS>
+__global__ void __launch_bounds__(256) pass2(uint64_t* __restrict__ d, size_t total) {
+    const size_t base = (size_t)blockIdx.x * 4096 + threadIdx.x * W;
+    uint64_t v[16 / W][W];
+#pragma unroll
+    for (int k = 0; k < 16 / W; ++k) ld<W, NTL>(d + base + (size_t)k * 256 * W, v[k]);
+#pragma unroll
+    for (int k = 0; k < 16 / W; ++k)
+#pragma unroll
+        for (int w = 0; w < W; ++w) v[k][w] = v[k][w] * 5 + v[(k + 1) % (16 / W)][w];
+#pragma unroll
+    for (int k = 0; k < 16 / W; ++k) st<W, NTS>(d + base + (size_t)k * 256 * W, v[k]);
+}
+
+template <class F> static float timed(F&& launch, hipEvent_t a, hipEvent_t b) {
+    std::vector<float> ms;
+    for (int rep = 0; rep < 7; ++rep) {
+        hipEventRecord(a); launch(); hipEventRecord(b); hipEventSynchronize(b);
+        float t; hipEventElapsedTime(&t, a, b); ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[ms.size() / 2];
+}
+
+int main() {
+    const size_t polys = 4096, n = 65536, total = polys * n, chunk_polys = 512, chunk = chunk_polys * n;
+    uint64_t* data;
+    CK(hipMalloc(&data, total * 8));
+    CK(hipMemset(data, 1, total * 8));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+#define RUN1(W, NTL, NTS) timed([&] { for (size_t c = 0; c < polys; c += chunk_polys) hipLaunchKernelGGL((pass1<W, NTL, NTS>), dim3((unsigned)(chunk / 16 / 256 / W)), dim3(256), 0, 0, data + c * n, chunk); }, a, b)
+#define RUN2(W, NTL, NTS) timed([&] { for (size_t c = 0; c < polys; c += chunk_polys) hipLaunchKernelGGL((pass2<W, NTL, NTS>), dim3((unsigned)(chunk / 4096)), dim3(256), 0, 0, data + c * n, chunk); }, a, b)
+#define RUNB(W1, L1, S1, W2, L2, S2) timed([&] { for (size_t c = 0; c < polys; c += chunk_polys) { \
+        hipLaunchKernelGGL((pass1<W1, L1, S1>), dim3((unsigned)(chunk / 16 / 256 / W1)), dim3(256), 0, 0, data + c * n, chunk); \
+        hipLaunchKernelGGL((pass2<W2, L2, S2>), dim3((unsigned)(chunk / 4096)), dim3(256), 0, 0, data + c * n, chunk); } }, a, b)
+    printf("per 4096 polynomials (2 GiB), in place, 512-polynomial chunks; ms (median of 7)\n");
+    printf("pass1 strided  8B  plain          %.3f\n", RUN1(1, false, false));
+    printf("pass1 strided 16B  plain          %.3f\n", RUN1(2, false, false));
+    printf("pass1 strided  8B  nt-load        %.3f\n", RUN1(1, true, false));
+    printf("pass1 strided 16B  nt-load        %.3f\n", RUN1(2, true, false));
+    printf("pass1 strided 16B  nt-load+store  %.3f\n", RUN1(2, true, true));
+    printf("pass2 tile     8B  plain          %.3f\n", RUN2(1, false, false));
+    printf("pass2 tile    16B  plain          %.3f\n", RUN2(2, false, false));
+    printf("pass2 tile     8B  nt-store       %.3f\n", RUN2(1, false, true));
+    printf("pass2 tile    16B  nt-store       %.3f\n", RUN2(2, false, true));
+    printf("pass2 tile    16B  nt-load+store  %.3f\n", RUN2(2, true, true));
+    printf("both   8B plain / 8B plain        %.3f   (round-1 floor: 1.29)\n", RUNB(1, false, false, 1, false, false));
+    printf("both  16B plain / 16B plain       %.3f\n", RUNB(2, false, false, 2, false, false));
+    printf("both  16B nt-load / 16B nt-store  %.3f\n", RUNB(2, true, false, 2, false, true));
+    printf("both   8B nt-load / 8B nt-store   %.3f\n", RUNB(1, true, false, 1, false, true));
+    printf("both   8B plain / 16B nt-load+store   %.3f\n", RUNB(1, false, false, 2, true, true));
+    printf("both   8B plain /  8B nt-load+store   %.3f\n", RUNB(1, false, false, 1, true, true));
+    printf("both   8B plain / 16B nt-load          %.3f\n", RUNB(1, false, false, 2, true, false));
+    printf("both   8B plain /  8B nt-load          %.3f\n", RUNB(1, false, false, 1, true, false));
+    printf("both   8B nt-load / 8B plain           %.3f\n", RUNB(1, true, false, 1, false, false));
+    printf("both   8B plain / 8B plain (again)     %.3f\n", RUNB(1, false, false, 1, false, false));
+    return 0;
+}
