@@ -59,7 +59,9 @@ int lsr_sample_gaussian_seeded(uint64_t* output, size_t len, double sigma, uint6
 size_t lsr_gaussian_cdf(double sigma, uint64_t* cdf, size_t cap) LSR_NOEXCEPT;
 
 /* ---------------- commitment: seeded contexts, batches, the metric workload ---------------- */
-/* lwe_context_create with an explicit key seed (0 = fresh entropy) and device (-1 = default) */
+/* lwe_context_create with an explicit key seed and device (-1 = default).  key_seed != 0: every key of the context is
+ * derived from it — reproducible contexts for tests and for replicating ONE context on several devices; such a context is
+ * only as secret as the 64-bit seed.  key_seed == 0: 256-bit OS entropy, exactly lwe_context_create. */
 LweContext* lsr_lwe_context_create_seeded(const PublicParams* params, uint64_t key_seed, int device) LSR_NOEXCEPT;
 uint64_t lsr_lwe_modulus(const LweContext* ctx) LSR_NOEXCEPT;         /* internal q actually used */
 uint64_t lsr_lwe_plain_modulus(const LweContext* ctx) LSR_NOEXCEPT;   /* t */
@@ -70,7 +72,7 @@ const NttContext* lsr_lwe_ntt_context(const LweContext* ctx) LSR_NOEXCEPT;
 /* copy the public matrix A_hat ([k][k][n], NTT domain) to a host buffer */
 int lsr_lwe_public_matrix(const LweContext* ctx, uint64_t* a_hat) LSR_NOEXCEPT;
 
-/* `batch` commitments in one device pass.  messages = [batch][msg_len]; seeds[batch] (0 = fresh);
+/* `batch` commitments in one device pass.  messages = [batch][msg_len]; seeds[batch] (0 = fresh; semantics of lwe_commit);
  * out[batch] receives commitments to be freed with lwe_commitment_free.  0 / -1. */
 int lwe_commit_batch(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch,
                      const uint64_t* seeds, LweCommitment** out) LSR_NOEXCEPT;
@@ -99,11 +101,24 @@ int lsr_lwe_verify_opening_batch_flat(const LweContext* ctx, const uint64_t* wor
 /* The Module-LWE matrix–vector workload of BASELINE config 3, device-resident:
  *   u_j = INTT( A_hat^T . NTT(r_j) ) + e1_j   for j < batch;   r, e1, u are [batch][k][n] in [0,q).
  * d_e1 != NULL: the blinding residues are read from it (seeds may be NULL).
- * d_e1 == NULL: e1 is sampled on the device, component i of vector j from the stream (seeds[j], domain 5, i);
+ * d_e1 == NULL: e1 is sampled on the device, component i of vector j from the raw-seed stream (seeds[j], domain 5, i)
+ *               (key = {seed, "LSR1", "STRM"}: a reproducible workload stream, not a commitment's message-bound key);
  *               `seeds` is then a HOST array of `batch` seeds and the call returns after the work has finished.
- * d_r is overwritten with NTT(r).  0 / -1. */
+ * d_r: contexts that qualify for the fused pipeline (FP64 flavour, n = 2^16 or 2^17, rank <= 4) only read it; otherwise it
+ * is overwritten with NTT(r) — treat its contents as unspecified after the call.  0 / -1. */
 int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u,
                                  size_t batch, const uint64_t* seeds, void* stream) LSR_NOEXCEPT;
+
+/* Field elements wider than the plaintext modulus t (about 2^20).  lwe_commit embeds every message word mod t — the
+ * reference's BatchEncoder takes out-of-range words unchecked and lwe_verify_opening compares the decoded slots with the
+ * message words as given (cpp-core/src/commitment.cpp:152,223-226), so there, as here, a word >= t is bound only through
+ * its residue and never opens.  A caller that needs a 44- or 64-bit coefficient bound in full commits to its LIMBS:
+ * limbs[i * limbs_per_word + l] = (words[i] >> (l * limb_bits)) & (2^limb_bits - 1), e.g. limb_bits = 16, limbs_per_word = 4
+ * (64-bit words) or limb_bits = 15, limbs_per_word = 3 (44-bit field); every limb is < t, the message grows by the factor
+ * limbs_per_word (<= ring_degree slots in all) and opens word for word.  Returns the number of limbs (count *
+ * limbs_per_word; also when `words` or `limbs` is NULL, for sizing), 0 on invalid limb parameters.  Host only. */
+size_t lsr_words_to_limbs(const uint64_t* words, size_t count, unsigned limb_bits, unsigned limbs_per_word,
+                          uint64_t* limbs) LSR_NOEXCEPT;
 
 /* The blinding residues alone: d_e1[batch][k][n] in [0,q), component i of vector j from the seeded CDT stream
  * (seeds[j], domain 5, i) — exactly what lsr_mlwe_matvec_batch_device samples when d_e1 == NULL.  `seeds` is a HOST

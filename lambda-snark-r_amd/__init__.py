@@ -270,6 +270,17 @@ class Commitment:
     __del__ = free
 
 
+def words_to_limbs(words, limb_bits=16, limbs_per_word=4):
+    """``lsr_words_to_limbs``: little-endian limbs of field elements wider than the plaintext modulus, so that a commitment
+    binds them in full (a message word >= t is embedded mod t and never opens — commitment.cpp:152,223-226)."""
+    lib = _abi.lib()
+    w = _u64_array(words, "words").ravel()
+    out = np.zeros(w.size * limbs_per_word, dtype=np.uint64)
+    if lib.lsr_words_to_limbs(w.ctypes.data, w.size, limb_bits, limbs_per_word, out.ctypes.data) != out.size:
+        raise ValueError("invalid limb parameters")
+    return out
+
+
 def verify_opening_with_context(ctx, commitment, message, randomness=None):
     """opening.rs:160-222 -> ``lwe_verify_opening``; returns True/False, raises on -1."""
     lib = _abi.lib()

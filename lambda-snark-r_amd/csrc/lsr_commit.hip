@@ -4,10 +4,12 @@
 // cpp-core/include/lambda_snark/commitment.h:43-52, which the SEAL-backed reference does not implement):
 //   context : A_hat in R_q^{k x k} uniform (NTT domain), s, e <- chi^k, b_hat = A_hat s_hat + e_hat,
 //             t = SEAL Batching(n,20) prime, Delta = floor(q/t)
-//   commit  : r, e1 <- chi^k, e2 <- chi (ChaCha20 stream of `seed`)
+//   commit  : r, e1 <- chi^k, e2 <- chi from the ChaCha20 streams of a per-commitment 256-bit key:
+//             PRF(seed, context id, embedded message) for seed != 0, OS entropy for seed == 0 (lsr_keys.hpp)
 //             u = INTT(A_hat^T r_hat) + e1                 (the matrix–vector + blinding-add workload)
 //             v = INTT(<b_hat, r_hat>) + e2 + Delta (m mod t)
-//   verify  : round(t/q (v - <s,u>)) mod t == m mod t       (trapdoor check, as the reference decrypts)
+//   verify  : round(t/q (v - <s,u>)) mod t == m, word for word (commitment.cpp:223-226: decoded ^ message, no reduction of
+//             the claimed message: a word >= t never opens)
 //   combine : sum_i (c_i mod t) (u_i, v_i)
 // Wire format: data[0] = payload bytes; payload = {"LSRC0001", n | k<<32, q, t, u[k][n], v[n]}.
 #include <algorithm>
@@ -22,6 +24,7 @@
 #include "lambda_snark/commitment.h"
 #include "lsr_arith.hpp"
 #include "lsr_commit_fused.hpp"
+#include "lsr_keys.hpp"
 #include "lsr_runtime.hpp"
 #include "lsr_sampler.hpp"
 
@@ -200,7 +203,7 @@ __device__ __forceinline__ uint64_t div128_by_q(uint64_t hi, uint64_t lo, const 
     return quot;
 }
 
-// flag |= OR_i ( round(t * w_i / q) mod t ) xor (msg_i mod t)   — OR-of-XOR compare of commitment.cpp:223-228
+// flag |= OR_i ( round(t * w_i / q) mod t ) xor msg_i   — OR-of-XOR compare of commitment.cpp:223-228
 __global__ void __launch_bounds__(256) decode_compare_kernel(const uint64_t* __restrict__ w, const uint64_t* __restrict__ msg, uint64_t msg_len,
                                                                uint64_t t, ModParams p, unsigned long long* __restrict__ flag) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -210,12 +213,12 @@ __global__ void __launch_bounds__(256) decode_compare_kernel(const uint64_t* __r
         const uint64_t lo = lo0 + (p.q >> 1);
         const uint64_t hi = hi0 + (lo < lo0);
         const uint64_t decoded = div128_by_q(hi, lo, p) % t;
-        diff = decoded ^ (msg[i] % t);
+        diff = decoded ^ msg[i];                       // raw message word (commitment.cpp:224)
     }
     if (diff) atomicOr(flag, (unsigned long long)diff);
 }
 
-// batched form: flags[j] |= OR_i decode(w[j][i]) xor (msg[j][i] mod t), one lane per (j, i)
+// batched form: flags[j] |= OR_i decode(w[j][i]) xor msg[j][i], one lane per (j, i)
 __global__ void __launch_bounds__(256) decode_compare_batch_kernel(const uint64_t* __restrict__ w, const uint64_t* __restrict__ msgs, uint64_t msg_len,
                                                                      uint32_t logn, uint64_t count, uint64_t t, ModParams p,
                                                                      unsigned long long* __restrict__ flags) {
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(256) decode_compare_batch_kernel(const uint64_
     const uint64_t lo0 = wi * t, hi0 = __umul64hi(wi, t);
     const uint64_t lo = lo0 + (p.q >> 1);
     const uint64_t hi = hi0 + (lo < lo0);
-    const uint64_t diff = (div128_by_q(hi, lo, p) % t) ^ (msgs[gid] % t);
+    const uint64_t diff = (div128_by_q(hi, lo, p) % t) ^ msgs[gid];
     if (diff) atomicOr(&flags[j], (unsigned long long)diff);
 }
 
@@ -250,12 +253,15 @@ struct LweContext {
     NttContext* ntt = nullptr;
     lsr::DeviceBuffer<uint64_t> a_hat, s_hat, b_hat, cdf;
     uint32_t cdf_entries = 0;
+    lsr::ContextKeys keys{};          // key schedule of this context (lsr_keys.hpp); keys.sec is secret
+    uint64_t key_seed = 0;            // what the context was created from (0 = OS entropy): lets a sharded run replicate it
+    double noise_unit = 0;            // 8 sqrt(2 k n) sigma^2: tail bound on the decoding noise of one fresh commitment
     // scratch for commit / verify / combine, grown on demand; guarded by `mutex`
     mutable std::mutex mutex;
-    mutable lsr::DeviceBuffer<uint64_t> ws_r, ws_e1, ws_e2, ws_u, ws_v, ws_dm, ws_seeds;
+    mutable lsr::DeviceBuffer<uint64_t> ws_r, ws_e1, ws_e2, ws_u, ws_v, ws_dm, ws_keys;   // ws_keys: [batch][4]
     mutable lsr::DeviceBuffer<unsigned long long> ws_flag;
     mutable size_t ws_batch = 0;
-    mutable std::vector<uint64_t> ws_seed_host;   // source of an asynchronous upload: must outlive the call that fills it
+    mutable std::vector<uint64_t> ws_key_host;    // source of an asynchronous upload: must outlive the call that fills it
     // pinned host staging for the gather of a batch (two bulk D2H copies instead of two per commitment)
     mutable uint64_t* host_stage = nullptr;
     mutable size_t host_stage_words = 0;
@@ -323,7 +329,7 @@ static void ensure_workspace(const LweContext& c, size_t batch) {
     c.ws_e2.allocate(batch * c.n);
     c.ws_v.allocate(batch * c.n);
     c.ws_dm.allocate(batch * c.n);   // message slots of a batch (at most n per commitment); verify's message buffer
-    c.ws_seeds.allocate(batch);
+    c.ws_keys.allocate(batch * 4);
     if (!c.ws_flag.ptr) c.ws_flag.allocate(1);
     c.ws_batch = batch;
 }
@@ -352,6 +358,16 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
     std::unique_ptr<LweContext> c(new LweContext);
     c->params = *params;
     c->q = q; c->t = t; c->delta = q / t; c->n = n; c->k = k; c->sigma = params->sigma;
+    // Noise budget: opening decodes round(t/q (Delta m + <e,r> - <s,e1> + e2)); the noise term is a sum of 2 k n products of
+    // two sigma-Gaussians, standard deviation sigma^2 sqrt(2 k n); with an 8-sigma tail it must stay below Delta / 2.
+    // A context whose FRESH commitments could fail to verify is refused here instead of failing silently later.
+    c->noise_unit = 8.0 * std::sqrt(2.0 * k * n) * params->sigma * params->sigma;
+    if (c->noise_unit >= 0.5 * static_cast<double>(c->delta)) {
+        set_last_error("lwe_context_create: sigma too large for the commitment modulus (noise budget Delta/2 exceeded); pass a wider NTT prime as modulus");
+        std::fprintf(stderr, "lwe_context_create error: sigma %.3f exceeds the noise budget of the %d-bit modulus at n=%u, k=%u\n", params->sigma,
+                     64 - __builtin_clzll(q), n, k);
+        return nullptr;
+    }
     c->ntt = create_ntt_context(q, n, device);
     if (!c->ntt) {
         std::fprintf(stderr, "lwe_context_create error: %s\n", last_error_cstr());
@@ -364,17 +380,19 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
         const std::vector<uint64_t> table = gaussian_cdf(c->sigma);
         c->cdf.upload(table);
         c->cdf_entries = static_cast<uint32_t>(table.size());
-        if (key_seed == 0) key_seed = os_entropy64() | 1ull;
+        c->key_seed = key_seed;
+        c->keys = derive_context_keys(key_seed);
         const size_t kn = (size_t)k * n;
         c->a_hat.allocate((size_t)k * kn);
         c->s_hat.allocate(kn);
         c->b_hat.allocate(kn);
-        DeviceBuffer<uint64_t> seed, e_hat(kn);
-        seed.upload(std::vector<uint64_t>{key_seed});
+        DeviceBuffer<uint64_t> pub_key, sec_key, e_hat(kn);
+        pub_key.upload(key_words(c->keys.pub));
+        sec_key.upload(key_words(c->keys.sec));
         hipStream_t s = c->ntt->stream;
-        launch_uniform(c->a_hat.ptr, seed.ptr, 0, k * k, kDomA, n, (uint64_t)k * k, q, s);
-        launch_gaussian(GaussianJob{c->s_hat.ptr, seed.ptr, 0, k, kDomS, n, k, q}, c->cdf.ptr, c->cdf_entries, s);
-        launch_gaussian(GaussianJob{e_hat.ptr, seed.ptr, 0, k, kDomE, n, k, q}, c->cdf.ptr, c->cdf_entries, s);
+        launch_uniform(c->a_hat.ptr, pub_key.ptr, 0, k * k, kDomA, n, (uint64_t)k * k, q, s);
+        launch_gaussian(GaussianJob{c->s_hat.ptr, sec_key.ptr, 0, k, kDomS, n, k, q}, c->cdf.ptr, c->cdf_entries, s);
+        launch_gaussian(GaussianJob{e_hat.ptr, sec_key.ptr, 0, k, kDomE, n, k, q}, c->cdf.ptr, c->cdf_entries, s);
         launch_ntt(*c->ntt, c->s_hat.ptr, k, false, s);
         launch_ntt(*c->ntt, e_hat.ptr, k, false, s);
         // b_hat[i] = sum_j A_hat[i][j] s_hat[j] + e_hat[i]
@@ -385,6 +403,7 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
             LSR_HIP(hipGetLastError());
         }
         LSR_HIP(hipStreamSynchronize(s));
+        LSR_HIP(hipMemset(sec_key.ptr, 0, 32));
     } catch (const std::exception& e) {
         set_last_error(std::string("lwe_context_create: ") + e.what());
         std::fprintf(stderr, "lwe_context_create error: %s\n", e.what());
@@ -399,12 +418,16 @@ static void destroy_lwe_context(LweContext* c) {
     try {
         DeviceGuard guard(c->device);
         // zeroize the secret key and the scratch that held commitment randomness (commitment.h:34)
-        for (lsr::DeviceBuffer<uint64_t>* b : {&c->s_hat, &c->ws_r, &c->ws_e1, &c->ws_e2})
+        volatile uint32_t* secret = c->keys.sec.w;
+        for (int i = 0; i < 8; ++i) secret[i] = 0;
+        volatile uint64_t* hk = c->ws_key_host.data();
+        for (size_t i = 0; i < c->ws_key_host.size(); ++i) hk[i] = 0;
+        for (lsr::DeviceBuffer<uint64_t>* b : {&c->s_hat, &c->ws_r, &c->ws_e1, &c->ws_e2, &c->ws_keys})
             if (b->ptr) (void)hipMemset(b->ptr, 0, b->count * 8);
         (void)hipDeviceSynchronize();
         c->a_hat.release(); c->s_hat.release(); c->b_hat.release(); c->cdf.release();
         c->ws_r.release(); c->ws_e1.release(); c->ws_e2.release(); c->ws_u.release(); c->ws_v.release();
-        c->ws_dm.release(); c->ws_seeds.release(); c->ws_flag.release();
+        c->ws_dm.release(); c->ws_keys.release(); c->ws_flag.release();
         c->a_perm.release(); c->ws_mid.release();
         for (int i = 0; i < c->n_side; ++i) {
             if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
@@ -517,12 +540,16 @@ static void commit_compute(const LweContext& c, const uint64_t* messages, size_t
     const uint32_t n = c.n, k = c.k;
     ensure_workspace(c, batch);
     hipStream_t s = c.ntt->stream;
-    // host prep: per-commit seeds (0 => fresh entropy, commitment.h:52) and Delta * (m mod t), truncated / zero-padded to n slots
-    std::vector<uint64_t>& seed_host = c.ws_seed_host;
-    seed_host.resize(batch);
+    // host prep: the per-commitment stream keys (lsr_keys.hpp): seed == 0 => 256 bits of fresh entropy (commitment.h:52), else
+    // PRF(seed, context id, embedded message) — a reused seed never repeats the blinding across messages or contexts
+    std::vector<uint64_t>& key_host = c.ws_key_host;
+    key_host.resize(batch * 4);
     const size_t copy = std::min<size_t>(msg_len, n);                       // commitment.cpp:146-149
-    for (size_t j = 0; j < batch; ++j) seed_host[j] = seeds && seeds[j] ? seeds[j] : (os_entropy64() | 1ull);
-    LSR_HIP(hipMemcpyAsync(c.ws_seeds.ptr, seed_host.data(), batch * 8, hipMemcpyHostToDevice, s));
+    for (size_t j = 0; j < batch; ++j) {
+        const StreamKey key = seeds && seeds[j] ? derive_commit_key(seeds[j], c.keys.id, messages + j * msg_len, copy, c.t) : fresh_key();
+        key_words(key, key_host.data() + 4 * j);
+    }
+    LSR_HIP(hipMemcpyAsync(c.ws_keys.ptr, key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
     // only the first `copy` slots of each message matter; rows keep their msg_len pitch
     DeviceBuffer<uint64_t> big_msgs;
     uint64_t* d_msgs = c.ws_dm.ptr;
@@ -531,9 +558,9 @@ static void commit_compute(const LweContext& c, const uint64_t* messages, size_t
         d_msgs = big_msgs.ptr;
     }
     if (copy) LSR_HIP(hipMemcpyAsync(d_msgs, messages, batch * msg_len * 8, hipMemcpyHostToDevice, s));
-    launch_gaussian(GaussianJob{c.ws_r.ptr, c.ws_seeds.ptr, 0, k, kDomR, n, batch * k, c.q}, c.cdf.ptr, c.cdf_entries, s);
-    launch_gaussian(GaussianJob{c.ws_e1.ptr, c.ws_seeds.ptr, 0, k, kDomE1, n, batch * k, c.q}, c.cdf.ptr, c.cdf_entries, s);
-    launch_gaussian(GaussianJob{c.ws_e2.ptr, c.ws_seeds.ptr, 0, 1, kDomE2, n, batch, c.q}, c.cdf.ptr, c.cdf_entries, s);
+    launch_gaussian(GaussianJob{c.ws_r.ptr, c.ws_keys.ptr, 0, k, kDomR, n, batch * k, c.q}, c.cdf.ptr, c.cdf_entries, s);
+    launch_gaussian(GaussianJob{c.ws_e1.ptr, c.ws_keys.ptr, 0, k, kDomE1, n, batch * k, c.q}, c.cdf.ptr, c.cdf_entries, s);
+    launch_gaussian(GaussianJob{c.ws_e2.ptr, c.ws_keys.ptr, 0, 1, kDomE2, n, batch, c.q}, c.cdf.ptr, c.cdf_entries, s);
     mlwe_matvec_device(c, c.ws_r.ptr, c.ws_e1.ptr, c.ws_u.ptr, batch, s);    // leaves r_hat in ws_r
     // v = INTT(<b_hat, r_hat>) + e2 + Delta m
     matvec(c, c.ws_v.ptr, c.b_hat.ptr, c.ws_r.ptr, nullptr, 1, k, 0, 1, batch, s);
@@ -826,6 +853,20 @@ static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** 
     uint64_t* const h_terms = c.host_stage;
     uint64_t* const h_coeffs = c.host_stage + group * body_words;
     LSR_HIP(hipMemsetAsync(acc.ptr, 0, body_words * 8, s));
+    // noise budget of the result: sum_i (c_i mod t) fresh-commitment noises must still decode (8-sigma tail below Delta / 2).
+    // The reference's 72-bit SEAL modulus absorbs any c_i < t (commitment.cpp:88-96,247-266); a 44-bit modulus does not, and a
+    // commitment that cannot open is refused here rather than returned.  A 60-bit NTT prime as params->modulus gives the
+    // reference's range.
+    double weight = 0;
+    for (size_t i = 0; i < count; ++i)
+        if (cms[i]) weight += static_cast<double>(coeffs[i] % c.t);
+    if (weight * c.noise_unit >= 0.5 * static_cast<double>(c.delta)) {
+        set_last_error("lwe_linear_combine: coefficients exceed the noise budget of this context's modulus (sum of c_i mod t too large); "
+                       "create the context with a wider NTT prime as modulus");
+        std::fprintf(stderr, "lwe_linear_combine error: sum of coefficients %.0f exceeds the noise budget %.0f of the %d-bit modulus\n", weight,
+                     0.5 * static_cast<double>(c.delta) / c.noise_unit, 64 - __builtin_clzll(c.q));
+        return nullptr;
+    }
     bool any = false;
     size_t staged = 0;
     auto flush = [&] {
@@ -879,9 +920,9 @@ extern "C" {
 
 LweContext* lwe_context_create(const PublicParams* params) noexcept {
     try {
-        uint64_t key_seed = 0;   // fresh key per context, like the reference (commitment.cpp:118-121)
-        if (const char* env = std::getenv("LAMBDA_SNARK_KEY_SEED")) key_seed = std::strtoull(env, nullptr, 0);
-        return lsr::create_lwe_context(params, key_seed, -1);
+        // fresh 256-bit keys per context, like the reference (commitment.cpp:118-121); reproducible keys only through the
+        // explicit entry point lsr_lwe_context_create_seeded
+        return lsr::create_lwe_context(params, 0, -1);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "lwe_context_create error: %s\n", e.what());
         return nullptr;
@@ -1070,16 +1111,30 @@ LweCommitment* lwe_linear_combine(const LweContext* ctx, const LweCommitment** c
     }
 }
 
+size_t lsr_words_to_limbs(const uint64_t* words, size_t count, unsigned limb_bits, unsigned limbs_per_word, uint64_t* limbs) noexcept {
+    if (limb_bits == 0 || limb_bits > 32 || limbs_per_word == 0 || limbs_per_word > 64) return 0;
+    if (!words || !limbs) return count * limbs_per_word;
+    const uint64_t mask = (1ull << limb_bits) - 1;
+    for (size_t i = 0; i < count; ++i)
+        for (unsigned l = 0; l < limbs_per_word; ++l) {
+            const unsigned shift = l * limb_bits;
+            limbs[i * limbs_per_word + l] = shift < 64 ? (words[i] >> shift) & mask : 0;
+        }
+    return count * limbs_per_word;
+}
+
 int lsr_lwe_sample_blinding_device(const LweContext* ctx, uint64_t* d_e1, size_t batch, const uint64_t* seeds, void* stream) noexcept {
     if (!ctx || !d_e1 || !seeds) return -1;
     if (batch == 0) return 0;
     try {
         lsr::DeviceGuard guard(ctx->device);
         hipStream_t s = static_cast<hipStream_t>(stream);
-        lsr::DeviceBuffer<uint64_t> d_seeds(batch);
-        LSR_HIP(hipMemcpyAsync(d_seeds.ptr, seeds, batch * 8, hipMemcpyHostToDevice, s));
-        lsr::launch_gaussian(lsr::GaussianJob{d_e1, d_seeds.ptr, 0, ctx->k, lsr::kDomE1, ctx->n, batch * ctx->k, ctx->q}, ctx->cdf.ptr, ctx->cdf_entries, s);
-        LSR_HIP(hipStreamSynchronize(s));   // d_seeds dies with this scope
+        std::vector<uint64_t> keys(batch * 4);
+        for (size_t j = 0; j < batch; ++j) lsr::key_words(lsr::expand_seed64(seeds[j]), keys.data() + 4 * j);
+        lsr::DeviceBuffer<uint64_t> d_keys(batch * 4);
+        LSR_HIP(hipMemcpyAsync(d_keys.ptr, keys.data(), batch * 32, hipMemcpyHostToDevice, s));
+        lsr::launch_gaussian(lsr::GaussianJob{d_e1, d_keys.ptr, 0, ctx->k, lsr::kDomE1, ctx->n, batch * ctx->k, ctx->q}, ctx->cdf.ptr, ctx->cdf_entries, s);
+        LSR_HIP(hipStreamSynchronize(s));   // the key arrays die with this scope
         return 0;
     } catch (const std::exception& e) {
         lsr::set_last_error(std::string("lsr_lwe_sample_blinding_device: ") + e.what());
@@ -1105,8 +1160,10 @@ int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uin
         }
         // e1 sampled on the device from the per-commit seeds (domain 5), then added
         lsr::ensure_workspace(*ctx, batch);
-        LSR_HIP(hipMemcpyAsync(ctx->ws_seeds.ptr, seeds, batch * 8, hipMemcpyHostToDevice, s));
-        lsr::launch_gaussian(lsr::GaussianJob{ctx->ws_e1.ptr, ctx->ws_seeds.ptr, 0, ctx->k, lsr::kDomE1, ctx->n, batch * ctx->k, ctx->q}, ctx->cdf.ptr,
+        ctx->ws_key_host.resize(batch * 4);
+        for (size_t j = 0; j < batch; ++j) lsr::key_words(lsr::expand_seed64(seeds[j]), ctx->ws_key_host.data() + 4 * j);
+        LSR_HIP(hipMemcpyAsync(ctx->ws_keys.ptr, ctx->ws_key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
+        lsr::launch_gaussian(lsr::GaussianJob{ctx->ws_e1.ptr, ctx->ws_keys.ptr, 0, ctx->k, lsr::kDomE1, ctx->n, batch * ctx->k, ctx->q}, ctx->cdf.ptr,
                              ctx->cdf_entries, s);
         lsr::mlwe_matvec_device(*ctx, d_r, ctx->ws_e1.ptr, d_u, batch, s, true);
         LSR_HIP(hipStreamSynchronize(s));   // seeds is a host array the caller may reuse

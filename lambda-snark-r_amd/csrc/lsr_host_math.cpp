@@ -1,4 +1,5 @@
 #include "lsr_host_math.hpp"
+#include "lsr_keys.hpp"
 
 #include <cmath>
 #include <limits>
@@ -195,8 +196,9 @@ uint64_t plain_modulus_for(uint32_t n) {
 }
 
 uint64_t os_entropy64() {
-    std::random_device rd;
-    return (static_cast<uint64_t>(rd()) << 32) ^ static_cast<uint64_t>(rd());
+    uint64_t v = 0;
+    os_entropy_fill(&v, sizeof v);
+    return v;
 }
 
 }  // namespace lsr

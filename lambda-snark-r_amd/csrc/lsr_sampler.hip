@@ -6,6 +6,7 @@
 
 #include "lambda_snark/batch.h"
 #include "lambda_snark/utils.h"
+#include "lsr_keys.hpp"
 #include "lsr_runtime.hpp"
 #include "lsr_sampler.hpp"
 
@@ -23,26 +24,28 @@ __global__ void __launch_bounds__(kSamplerThreads) gaussian_kernel(GaussianJob j
     if (gid >= blocks_per_object * job.objects) return;
     const uint64_t object = gid / blocks_per_object;
     const uint64_t block = gid - object * blocks_per_object;
-    const uint64_t seed = job.seeds[object / job.components];
     const uint64_t index = job.index_base + object % job.components;
     uint64_t w[8];
-    stream_block(seed, job.domain, index, (uint32_t)block, w);
+    stream_block(job.keys + 4 * (object / job.components), job.domain, index, (uint32_t)block, w);
     uint64_t* dst = job.out + object * job.samples + block * 4;
     const uint64_t left = job.samples - block * 4;
+    const uint64_t u[4] = {w[0], w[2], w[4], w[6]};
+    uint32_t magnitude[4];
+    cdt_scan<4>(cdf, entries, u, magnitude);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         if ((uint64_t)s >= left) break;
-        const uint32_t magnitude = cdt_lookup(cdf, entries, w[2 * s]);
-        const bool negative = (w[2 * s + 1] & 1ull) && magnitude != 0;
+        const uint64_t m = magnitude[s];
+        const uint64_t sign = (w[2 * s + 1] & 1ull) & (uint64_t)(m != 0);      // branch-free sign (utils.cpp:114-120)
         uint64_t value;
-        if (job.q) value = negative ? job.q - magnitude : (uint64_t)magnitude;
-        else value = negative ? (uint64_t)(-(int64_t)magnitude) : (uint64_t)magnitude;
+        if (job.q) value = sign ? job.q - m : m;
+        else value = (m ^ (0ull - sign)) + sign;                                // two's complement of m when sign is set
         dst[s] = value;
     }
 }
 
 // One lane = one ChaCha block = eight uniform residues.
-__global__ void __launch_bounds__(kSamplerThreads) uniform_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ seeds, uint64_t index_base,
+__global__ void __launch_bounds__(kSamplerThreads) uniform_kernel(uint64_t* __restrict__ out, const uint64_t* __restrict__ keys, uint64_t index_base,
                                                                     uint32_t components, uint32_t domain, uint64_t samples, uint64_t objects, uint64_t q) {
     const uint64_t blocks_per_object = (samples + 7) >> 3;
     const uint64_t gid = (uint64_t)blockIdx.x * kSamplerThreads + threadIdx.x;
@@ -50,7 +53,7 @@ __global__ void __launch_bounds__(kSamplerThreads) uniform_kernel(uint64_t* __re
     const uint64_t object = gid / blocks_per_object;
     const uint64_t block = gid - object * blocks_per_object;
     uint64_t w[8];
-    stream_block(seeds[object / components], domain, index_base + object % components, (uint32_t)block, w);
+    stream_block(keys + 4 * (object / components), domain, index_base + object % components, (uint32_t)block, w);
     uint64_t* dst = out + object * samples + block * 8;
     const uint64_t left = samples - block * 8;
 #pragma unroll
@@ -81,12 +84,12 @@ void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t ent
     LSR_HIP(hipGetLastError());
 }
 
-void launch_uniform(uint64_t* out, const uint64_t* d_seeds, uint64_t index_base, uint32_t components, uint32_t domain, uint64_t samples,
+void launch_uniform(uint64_t* out, const uint64_t* d_keys, uint64_t index_base, uint32_t components, uint32_t domain, uint64_t samples,
                     uint64_t objects, uint64_t q, hipStream_t stream) {
     const uint64_t lanes = ((samples + 7) >> 3) * objects;
     if (!lanes) return;
     const unsigned grid = static_cast<unsigned>((lanes + kSamplerThreads - 1) / kSamplerThreads);
-    hipLaunchKernelGGL(uniform_kernel, dim3(grid), dim3(kSamplerThreads), 0, stream, out, d_seeds, index_base, components, domain, samples, objects, q);
+    hipLaunchKernelGGL(uniform_kernel, dim3(grid), dim3(kSamplerThreads), 0, stream, out, d_keys, index_base, components, domain, samples, objects, q);
     LSR_HIP(hipGetLastError());
 }
 
@@ -97,10 +100,10 @@ static int sample_to_host(uint64_t* output, size_t len, double sigma, uint64_t s
     if ((len + 3) / 4 > 0xFFFFFFFFull) throw std::runtime_error("len exceeds one stream (2^34 samples)");
     if (visible_device_count() <= 0) throw std::runtime_error("no HIP device visible — no CPU fallback");
     DeviceGuard guard(default_device());
-    DeviceBuffer<uint64_t> d_cdf, d_seed, d_out(len);
+    DeviceBuffer<uint64_t> d_cdf, d_key, d_out(len);
     d_cdf.upload(table);
-    d_seed.upload(std::vector<uint64_t>{seed});
-    GaussianJob job{d_out.ptr, d_seed.ptr, index, 1, domain, len, 1, 0};
+    d_key.upload(key_words(expand_seed64(seed)));
+    GaussianJob job{d_out.ptr, d_key.ptr, index, 1, domain, len, 1, 0};
     launch_gaussian(job, d_cdf.ptr, static_cast<uint32_t>(table.size()), nullptr);
     LSR_HIP(hipMemcpy(output, d_out.ptr, len * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
@@ -114,6 +117,8 @@ int sample_gaussian(uint64_t* output, size_t len, double sigma) noexcept {
     if (!output || len == 0 || !(sigma > 0.0) || !std::isfinite(sigma)) return -1;   // utils.cpp:133
     try {
         // fresh entropy per call, as the reference's std::random_device (utils.cpp:138)
+        // (the raw-seed stream carries 64 bits of entropy per call plus a random stream index; the reference's sampler is a
+        // test utility too — commitment.cpp never calls it)
         return lsr::sample_to_host(output, len, sigma, lsr::os_entropy64(), lsr::kDomUser, lsr::os_entropy64());
     } catch (const std::exception& e) {
         lsr::set_last_error(std::string("sample_gaussian: ") + e.what());

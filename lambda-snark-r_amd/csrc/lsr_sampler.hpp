@@ -3,9 +3,10 @@
 // The reference sampler (cpp-core/src/utils.cpp:95-146) draws two 64-bit words per sample from
 // std::random_device: one compared against the CDT table (first k with cdf[k] >= u), one whose low bit is
 // the sign.  Here the words come from a counter-based ChaCha20 stream so that a seed reproduces the
-// output on any device: object (seed, domain, index) owns a stream; 64-bit word w of it is ChaCha block
+// output on any device: object (key, domain, index) owns a stream; 64-bit word w of it is ChaCha block
 // w/8, 32-bit words 2(w%8) (low half) and 2(w%8)+1 (high half); sample i uses words 2i and 2i+1.
-//   key   = { seed_lo, seed_hi, "LSR1", "STRM", 0, 0, 0, 0 }
+//   key   = 256 bits from the key schedule of lsr_keys.hpp (per context / per commitment), or the expansion
+//           { seed_lo, seed_hi, "LSR1", "STRM", 0, 0, 0, 0 } of a raw 64-bit test seed
 //   nonce = { domain, index_lo, index_hi }          counter = block number
 #pragma once
 
@@ -26,10 +27,12 @@ __device__ __forceinline__ void chacha_quarter(uint32_t& a, uint32_t& b, uint32_
 }
 
 // RFC 8439 §2.3 block function; returns the block as eight little-endian 64-bit words.
-__device__ __forceinline__ void stream_block(uint64_t seed, uint32_t domain, uint64_t index, uint32_t block, uint64_t (&w)[8]) {
+// key4: the 256-bit key as four little-endian 64-bit words
+__device__ __forceinline__ void stream_block(const uint64_t* __restrict__ key4, uint32_t domain, uint64_t index, uint32_t block, uint64_t (&w)[8]) {
+    const uint64_t k0 = key4[0], k1 = key4[1], k2 = key4[2], k3 = key4[3];
     const uint32_t init[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
-                               (uint32_t)seed, (uint32_t)(seed >> 32), 0x3152534Cu, 0x4D525453u, 0u, 0u, 0u, 0u,
-                               block, domain, (uint32_t)index, (uint32_t)(index >> 32)};
+                               (uint32_t)k0, (uint32_t)(k0 >> 32), (uint32_t)k1, (uint32_t)(k1 >> 32), (uint32_t)k2, (uint32_t)(k2 >> 32),
+                               (uint32_t)k3, (uint32_t)(k3 >> 32), block, domain, (uint32_t)index, (uint32_t)(index >> 32)};
     uint32_t x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = init[i];
@@ -48,21 +51,24 @@ __device__ __forceinline__ void stream_block(uint64_t seed, uint32_t domain, uin
     for (int j = 0; j < 8; ++j) w[j] = (uint64_t)(x[2 * j] + init[2 * j]) | ((uint64_t)(x[2 * j + 1] + init[2 * j + 1]) << 32);
 }
 
-// first k with cdf[k] >= u (cdf non-decreasing, cdf[entries-1] == 2^64-1) — same value the reference's
-// branch-free scan selects (utils.cpp:101-108)
-__device__ __forceinline__ uint32_t cdt_lookup(const uint64_t* cdf, uint32_t entries, uint64_t u) {
-    uint32_t lo = 0, hi = entries - 1;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (cdf[mid] >= u) hi = mid;
-        else lo = mid + 1;
+// Magnitudes of COUNT samples at once: first k with cdf[k] >= u[s] (cdf non-decreasing, cdf[entries-1] == 2^64-1) — the value the
+// reference's scan selects (utils.cpp:101-108) — computed the way the reference computes it: a branch-free pass over the
+// WHOLE table, count += (cdf[k] < u).  Every lane reads the same LDS word per step (a broadcast), so neither the
+// instruction stream nor the LDS access pattern depends on the secret uniform words.
+template <int COUNT>
+__device__ __forceinline__ void cdt_scan(const uint64_t* cdf, uint32_t entries, const uint64_t (&u)[COUNT], uint32_t (&magnitude)[COUNT]) {
+#pragma unroll
+    for (int s = 0; s < COUNT; ++s) magnitude[s] = 0;
+    for (uint32_t k = 0; k + 1 < entries; ++k) {      // the last entry is 2^64 - 1: never below u
+        const uint64_t c = cdf[k];
+#pragma unroll
+        for (int s = 0; s < COUNT; ++s) magnitude[s] += (c < u[s]) ? 1u : 0u;
     }
-    return lo;
 }
 
 struct GaussianJob {
     uint64_t* out;            // [objects][samples]
-    const uint64_t* seeds;    // device array; object o uses seeds[o / components]
+    const uint64_t* keys;     // device array [groups][4]: the 256-bit stream key of object o is keys[4 (o / components) ..]
     uint64_t index_base;      // stream index of object o = index_base + o % components
     uint32_t components;
     uint32_t domain;
@@ -72,8 +78,8 @@ struct GaussianJob {
 };
 
 void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream);
-// out[o][i] = floor(word_i * q / 2^64), object o = (seeds[o / components], domain, index_base + o % components)
-void launch_uniform(uint64_t* out, const uint64_t* d_seeds, uint64_t index_base, uint32_t components, uint32_t domain,
+// out[o][i] = floor(word_i * q / 2^64), object o = (keys[4 (o / components) ..], domain, index_base + o % components)
+void launch_uniform(uint64_t* out, const uint64_t* d_keys, uint64_t index_base, uint32_t components, uint32_t domain,
                     uint64_t samples, uint64_t objects, uint64_t q, hipStream_t stream);
 
 }  // namespace lsr

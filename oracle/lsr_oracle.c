@@ -321,13 +321,58 @@ void oracle_chacha20_block(const uint32_t key[8], uint32_t counter, const uint32
     for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
 }
 
-/* key = {seed_lo, seed_hi, 'LSR1', 'STRM', 0,0,0,0}; nonce = {domain, index_lo, index_hi}; counter = block */
-static void stream_block(uint64_t seed, uint32_t domain, uint64_t index, uint32_t block, uint64_t w[8]) {
-    const uint32_t key[8] = {(uint32_t)seed, (uint32_t)(seed >> 32), 0x3152534Cu, 0x4D525453u, 0, 0, 0, 0};
+/* a stream is (256-bit key, domain, index): nonce = {domain, index_lo, index_hi}; counter = block */
+static void key_block(const uint32_t key[8], uint32_t domain, uint64_t index, uint32_t block, uint64_t w[8]) {
     const uint32_t nonce[3] = {domain, (uint32_t)index, (uint32_t)(index >> 32)};
     uint32_t o[16];
     oracle_chacha20_block(key, block, nonce, o);
     for (int j = 0; j < 8; ++j) w[j] = (uint64_t)o[2 * j] | ((uint64_t)o[2 * j + 1] << 32);
+}
+/* raw 64-bit test seed: key = {seed_lo, seed_hi, 'LSR1', 'STRM', 0,0,0,0} */
+static void expand_seed(uint64_t seed, uint32_t key[8]) {
+    const uint32_t k[8] = {(uint32_t)seed, (uint32_t)(seed >> 32), 0x3152534Cu, 0x4D525453u, 0, 0, 0, 0};
+    memcpy(key, k, sizeof k);
+}
+static void stream_block(uint64_t seed, uint32_t domain, uint64_t index, uint32_t block, uint64_t w[8]) {
+    uint32_t key[8];
+    expand_seed(seed, key);
+    key_block(key, domain, index, block, w);
+}
+
+/* ---- key schedule (restates the library's definition, DESIGN.md "Commitment definition"; there is no reference
+ * counterpart: cpp-core/src/commitment.cpp:141-157 ignores `seed` and draws fresh SEAL randomness) ---- */
+#define TAG(a, b, c, d) ((uint32_t)(a) | ((uint32_t)(b) << 8) | ((uint32_t)(c) << 16) | ((uint32_t)(d) << 24))
+static void kdf(const uint32_t key[8], uint32_t label, uint32_t a, uint32_t b, uint32_t c, uint32_t out[8]) {
+    const uint32_t nonce[3] = {a, b, c};
+    uint32_t o[16];
+    oracle_chacha20_block(key, label, nonce, o);
+    memcpy(out, o, 8 * sizeof(uint32_t));
+}
+void oracle_context_keys(uint64_t key_seed, uint32_t pub[8], uint32_t sec[8], uint32_t id[4]) {
+    const uint32_t master[8] = {(uint32_t)key_seed, (uint32_t)(key_seed >> 32), TAG('L', 'S', 'R', '2'), TAG('M', 'S', 'T', 'R'), 0, 0, 0, 0};
+    uint32_t idk[8];
+    kdf(master, TAG('P', 'U', 'B', 'K'), 0, 0, 0, pub);
+    kdf(master, TAG('S', 'E', 'C', 'K'), 0, 0, 0, sec);
+    kdf(sec, TAG('C', 'T', 'I', 'D'), pub[0], pub[1], pub[2], idk);
+    memcpy(id, idk, 4 * sizeof(uint32_t));
+}
+static const uint64_t P61 = ((uint64_t)1 << 61) - 1;
+static uint64_t mul61(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) % P61); }
+void oracle_commit_key(uint64_t seed, const uint32_t id[4], const uint64_t* msg, size_t copy, uint64_t t, uint32_t out[8]) {
+    const uint32_t base[8] = {(uint32_t)seed, (uint32_t)(seed >> 32), TAG('L', 'S', 'R', '2'), TAG('C', 'M', 'I', 'T'), id[0], id[1], id[2], id[3]};
+    uint32_t pts[8], step[8];
+    kdf(base, TAG('H', 'P', 'N', 'T'), 0, 0, 0, pts);
+    const uint64_t x1 = ((((uint64_t)pts[1] << 32) | pts[0]) & P61) % P61, x2 = ((((uint64_t)pts[3] << 32) | pts[2]) & P61) % P61;
+    uint64_t h1 = 0, h2 = 0, p1 = x1, p2 = x2;
+    for (size_t i = 0; i < copy; ++i) {
+        const uint64_t m = msg[i] % t;
+        h1 = (h1 + mul61(m, p1)) % P61;
+        h2 = (h2 + mul61(m, p2)) % P61;
+        p1 = mul61(p1, x1);
+        p2 = mul61(p2, x2);
+    }
+    kdf(base, TAG('C', 'K', 'Y', '1'), (uint32_t)h1, (uint32_t)(h1 >> 32), 0, step);
+    kdf(step, TAG('C', 'K', 'Y', '2'), (uint32_t)h2, (uint32_t)(h2 >> 32), 0, out);
 }
 
 void oracle_stream_words(uint64_t seed, uint32_t domain, uint64_t index, uint64_t first, uint64_t* out, size_t count) {
@@ -406,17 +451,22 @@ int oracle_sample_gaussian(uint64_t* out, size_t len, double sigma) {
     return 0;
 }
 
-int oracle_sample_gaussian_seeded(uint64_t* out, size_t len, double sigma, uint64_t seed, uint32_t domain, uint64_t index) {
+static int sample_gaussian_keyed(uint64_t* out, size_t len, double sigma, const uint32_t key[8], uint32_t domain, uint64_t index) {
     if (!out || len == 0 || !(sigma > 0.0) || !isfinite(sigma)) return -1;
     uint64_t cdf[4096];
     size_t entries = oracle_gaussian_cdf(sigma, cdf, 4096);
     if (!entries) return -1;
     uint64_t w[8];
     for (size_t i = 0; i < len; ++i) {
-        if ((i & 3) == 0) stream_block(seed, domain, index, (uint32_t)(i >> 2), w);
+        if ((i & 3) == 0) key_block(key, domain, index, (uint32_t)(i >> 2), w);
         out[i] = (uint64_t)cdt_pick(cdf, entries, w[2 * (i & 3)], w[2 * (i & 3) + 1]);
     }
     return 0;
+}
+int oracle_sample_gaussian_seeded(uint64_t* out, size_t len, double sigma, uint64_t seed, uint32_t domain, uint64_t index) {
+    uint32_t key[8];
+    expand_seed(seed, key);
+    return sample_gaussian_keyed(out, len, sigma, key, domain, index);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -430,6 +480,8 @@ struct oracle_lwe {
     uint64_t q, t, delta;
     uint32_t n, k;
     double sigma;
+    double noise_unit;           /* 8 sqrt(2 k n) sigma^2 */
+    uint32_t pub[8], sec[8], id[4];
     oracle_ntt* ntt;
     uint64_t* a_hat;   /* [k][k][n], NTT domain */
     uint64_t* s_hat;   /* [k][n], NTT domain   */
@@ -443,16 +495,16 @@ uint64_t oracle_lwe_select_modulus(uint64_t req, uint32_t n) {
     return oracle_largest_prime_1mod(2ull * n, 44);       /* n=2^16 -> 17592182243329 */
 }
 
-static void uniform_poly(uint64_t seed, uint32_t domain, uint64_t index, uint64_t q, uint64_t* out, uint32_t n) {
+static void uniform_poly(const uint32_t key[8], uint32_t domain, uint64_t index, uint64_t q, uint64_t* out, uint32_t n) {
     uint64_t w[8];
     for (uint32_t i = 0; i < n; ++i) {
-        if ((i & 7) == 0) stream_block(seed, domain, index, i >> 3, w);
+        if ((i & 7) == 0) key_block(key, domain, index, i >> 3, w);
         out[i] = (uint64_t)(((u128)w[i & 7] * q) >> 64);
     }
 }
 
-static void gaussian_poly(uint64_t seed, uint32_t domain, uint64_t index, double sigma, uint64_t q, uint64_t* out, uint32_t n) {
-    oracle_sample_gaussian_seeded(out, n, sigma, seed, domain, index);
+static void gaussian_poly(const uint32_t key[8], uint32_t domain, uint64_t index, double sigma, uint64_t q, uint64_t* out, uint32_t n) {
+    sample_gaussian_keyed(out, n, sigma, key, domain, index);
     for (uint32_t i = 0; i < n; ++i) {
         int64_t v = (int64_t)out[i];
         out[i] = v < 0 ? q - (uint64_t)(-v) : (uint64_t)v;
@@ -468,6 +520,9 @@ oracle_lwe* oracle_lwe_create(uint64_t req_q, uint32_t n, uint32_t k, double sig
     if (!t) return NULL;
     oracle_lwe* c = (oracle_lwe*)calloc(1, sizeof *c);
     c->q = q; c->t = t; c->delta = q / t; c->n = n; c->k = k; c->sigma = sigma;
+    c->noise_unit = 8.0 * sqrt(2.0 * k * n) * sigma * sigma;
+    if (c->noise_unit >= 0.5 * (double)c->delta) { free(c); return NULL; }   /* fresh commitments could fail to open */
+    oracle_context_keys(key_seed, c->pub, c->sec, c->id);
     c->ntt = oracle_ntt_create(q, n);
     if (!c->ntt) { free(c); return NULL; }
     c->a_hat = (uint64_t*)malloc(sizeof(uint64_t) * k * k * n);
@@ -475,14 +530,14 @@ oracle_lwe* oracle_lwe_create(uint64_t req_q, uint32_t n, uint32_t k, double sig
     c->b_hat = (uint64_t*)malloc(sizeof(uint64_t) * k * n);
     uint64_t* tmp = (uint64_t*)malloc(sizeof(uint64_t) * n);
     for (uint32_t i = 0; i < k; ++i)
-        for (uint32_t j = 0; j < k; ++j) uniform_poly(key_seed, DOM_A, (uint64_t)i * k + j, q, c->a_hat + ((size_t)i * k + j) * n, n);
+        for (uint32_t j = 0; j < k; ++j) uniform_poly(c->pub, DOM_A, (uint64_t)i * k + j, q, c->a_hat + ((size_t)i * k + j) * n, n);
     for (uint32_t j = 0; j < k; ++j) {
-        gaussian_poly(key_seed, DOM_S, j, sigma, q, c->s_hat + (size_t)j * n, n);
+        gaussian_poly(c->sec, DOM_S, j, sigma, q, c->s_hat + (size_t)j * n, n);
         fwd_core(c->ntt, c->s_hat + (size_t)j * n);
     }
     for (uint32_t i = 0; i < k; ++i) {
         uint64_t* b = c->b_hat + (size_t)i * n;
-        gaussian_poly(key_seed, DOM_E, i, sigma, q, b, n);
+        gaussian_poly(c->sec, DOM_E, i, sigma, q, b, n);
         fwd_core(c->ntt, b);
         for (uint32_t j = 0; j < k; ++j) {
             const uint64_t* a = c->a_hat + ((size_t)i * k + j) * n;
@@ -533,11 +588,15 @@ int oracle_lwe_commit(const oracle_lwe* c, const uint64_t* msg, size_t msg_len, 
     uint64_t* r = (uint64_t*)malloc(sizeof(uint64_t) * k * n);
     uint64_t* e1 = (uint64_t*)malloc(sizeof(uint64_t) * k * n);
     uint64_t* e2 = (uint64_t*)malloc(sizeof(uint64_t) * n);
+    /* per-commitment key = PRF(seed, context id, embedded message); seed == 0 means fresh entropy in the library and has no
+       deterministic counterpart — the oracle then uses the all-zero seed's key like any other */
+    uint32_t ck[8];
+    oracle_commit_key(seed, c->id, msg, msg_len < n ? msg_len : n, c->t, ck);
     for (uint32_t i = 0; i < k; ++i) {
-        gaussian_poly(seed, DOM_R, i, c->sigma, q, r + (size_t)i * n, n);
-        gaussian_poly(seed, DOM_E1, i, c->sigma, q, e1 + (size_t)i * n, n);
+        gaussian_poly(ck, DOM_R, i, c->sigma, q, r + (size_t)i * n, n);
+        gaussian_poly(ck, DOM_E1, i, c->sigma, q, e1 + (size_t)i * n, n);
     }
-    gaussian_poly(seed, DOM_E2, 0, c->sigma, q, e2, n);
+    gaussian_poly(ck, DOM_E2, 0, c->sigma, q, e2, n);
     out[0] = 8ull * (4 + (size_t)(k + 1) * n);
     out[1] = kMagic;
     out[2] = (uint64_t)n | ((uint64_t)k << 32);
@@ -596,7 +655,7 @@ int oracle_lwe_verify(const oracle_lwe* c, const uint64_t* comm, size_t comm_len
     uint64_t diff = 0;
     for (size_t i = 0; i < msg_len; ++i) {
         uint64_t dec = (uint64_t)((((u128)w[i] * c->t) + (q >> 1)) / q) % c->t;
-        diff |= dec ^ (msg[i] % c->t);
+        diff |= dec ^ msg[i];                                       /* raw message word, commitment.cpp:224 */
     }
     free(w); free(tmp);
     return diff == 0 ? 1 : 0;
@@ -606,6 +665,10 @@ int oracle_lwe_linear_combine(const oracle_lwe* c, const uint64_t* const* comms,
     if (!c || !comms || !coeffs || count == 0 || !out) return -1;   /* commitment.cpp:240-242 */
     const size_t body = (size_t)(c->k + 1) * c->n;
     int has = 0;
+    double weight = 0;
+    for (size_t i = 0; i < count; ++i)
+        if (comms[i]) weight += (double)(coeffs[i] % c->t);
+    if (weight * c->noise_unit >= 0.5 * (double)c->delta) return -1;  /* the result could not be opened (noise budget) */
     memset(out, 0, sizeof(uint64_t) * (5 + body));
     for (size_t i = 0; i < count; ++i) {
         if (!comms[i]) continue;                                    /* commitment.cpp:248-250 */

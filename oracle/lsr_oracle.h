@@ -85,6 +85,9 @@ int oracle_sample_gaussian_seeded(uint64_t* out, size_t len, double sigma, uint6
 /* ---------- Module-LWE commitment (definition: DESIGN.md §commitment) ---------- */
 typedef struct oracle_lwe oracle_lwe;
 /* internal parameter selection */
+/* key schedule: context keys from a non-zero key seed; per-commitment key = PRF(seed, id, embedded message) */
+void oracle_context_keys(uint64_t key_seed, uint32_t pub[8], uint32_t sec[8], uint32_t id[4]);
+void oracle_commit_key(uint64_t seed, const uint32_t id[4], const uint64_t* msg, size_t copy, uint64_t t, uint32_t out[8]);
 uint64_t oracle_lwe_select_modulus(uint64_t requested_q, uint32_t n);
 oracle_lwe* oracle_lwe_create(uint64_t requested_q, uint32_t n, uint32_t k, double sigma, uint64_t key_seed);
 void        oracle_lwe_free(oracle_lwe* c);

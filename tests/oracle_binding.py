@@ -36,6 +36,8 @@ class Oracle:
         L.oracle_gaussian_cdf.restype = sz; L.oracle_gaussian_cdf.argtypes = [dbl, vp, sz]
         L.oracle_sample_gaussian.restype = ci; L.oracle_sample_gaussian.argtypes = [vp, sz, dbl]
         L.oracle_sample_gaussian_seeded.restype = ci; L.oracle_sample_gaussian_seeded.argtypes = [vp, sz, dbl, u64, u32, u64]
+        L.oracle_context_keys.argtypes = [u64, vp, vp, vp]
+        L.oracle_commit_key.argtypes = [u64, vp, vp, sz, u64, vp]
         L.oracle_lwe_select_modulus.restype = u64; L.oracle_lwe_select_modulus.argtypes = [u64, u32]
         L.oracle_lwe_create.restype = vp; L.oracle_lwe_create.argtypes = [u64, u32, u32, dbl, u64]
         L.oracle_lwe_free.argtypes = [vp]
@@ -135,6 +137,18 @@ class Oracle:
         if key not in self._lwe:
             self._lwe[key] = self.L.oracle_lwe_create(q, n, k, sigma, key_seed)
         return self._lwe[key]
+
+    def context_keys(self, key_seed):
+        pub, sec, ident = (np.zeros(8, dtype=np.uint32), np.zeros(8, dtype=np.uint32), np.zeros(4, dtype=np.uint32))
+        self.L.oracle_context_keys(key_seed, pub.ctypes.data, sec.ctypes.data, ident.ctypes.data)
+        return pub, sec, ident
+
+    def commit_key(self, seed, ident, msg, t):
+        m = np.array([int(x) for x in msg] or [0], dtype=np.uint64)
+        ident = np.ascontiguousarray(ident, dtype=np.uint32)
+        out = np.zeros(8, dtype=np.uint32)
+        self.L.oracle_commit_key(seed, ident.ctypes.data, m.ctypes.data, len(msg), t, out.ctypes.data)
+        return out
 
     def lwe_commit(self, q, n, k, sigma, key_seed, msg, seed):
         h = self.lwe_handle(q, n, k, sigma, key_seed)

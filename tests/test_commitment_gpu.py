@@ -183,8 +183,13 @@ def test_commit_bit_exact_vs_oracle(pkg, oracle, q, n, k):
         got = words(p)
         assert np.array_equal(got, want)
         shown = msg[:n]
-        assert lctx._lib.lwe_verify_opening(lctx.handle, p, np.array(shown, np.uint64).ctypes.data, len(shown), None) == 1
-        assert oracle.lwe_verify(q, n, k, 3.19, KEY, got, shown) == 1
+        t = lctx.plain_modulus
+        opens = 1 if all(x < t for x in shown) else 0          # words >= t are embedded mod t and never open as given (commitment.cpp:223-226)
+        assert lctx._lib.lwe_verify_opening(lctx.handle, p, np.array(shown, np.uint64).ctypes.data, len(shown), None) == opens
+        assert oracle.lwe_verify(q, n, k, 3.19, KEY, got, shown) == opens
+        canonical = [x % t for x in shown]
+        assert lctx._lib.lwe_verify_opening(lctx.handle, p, np.array(canonical, np.uint64).ctypes.data, len(canonical), None) == 1
+        assert oracle.lwe_verify(q, n, k, 3.19, KEY, got, canonical) == 1
         lctx._lib.lwe_commitment_free(p)
     lctx.close()
 
@@ -221,7 +226,7 @@ def test_commit_batch_flat_equals_per_commitment_form(pkg, oracle, lib, monkeypa
     ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=key)
     rng = np.random.default_rng(31)
     batch = 37
-    msgs = rng.integers(0, 2**20, size=(batch, 9), dtype=np.uint64)
+    msgs = rng.integers(0, ctx.plain_modulus, size=(batch, 9), dtype=np.uint64)
     seeds = rng.integers(1, 2**62, size=batch, dtype=np.uint64)
     flat = pkg.Commitment.batch_words(ctx, msgs, seeds)
     assert flat.shape == (batch, 5 + (k + 1) * n)
@@ -416,7 +421,7 @@ def test_empty_message_and_zero_length_openings(pkg, lib, oracle):
     lctx.close()
 
 
-def test_large_combination_coefficients_need_a_wide_modulus(pkg):
+def test_large_combination_coefficients_need_a_wide_modulus(pkg, oracle):
     """with the 44-bit internal modulus the noise budget admits sum(c_i) up to ~2^10; a caller that
     combines with coefficients as large as the plaintext modulus (the reference's 72-bit SEAL modulus allows that,
     commitment.cpp:88-96) passes a 60-bit NTT prime as params->modulus, which the library honours."""
@@ -434,9 +439,63 @@ def test_large_combination_coefficients_need_a_wide_modulus(pkg):
     wide.close()
     narrow = pkg.LweContext(pkg.Params(q=17592186044417, n=4096, k=2, sigma=3.19), key_seed=5)
     coms = [pkg.Commitment(narrow, m, seed=10 + i) for i, m in enumerate(msgs)]
-    small = pkg.Commitment.linear_combine(narrow, coms, [200, 300, 400])
-    assert pkg.verify_opening_with_context(narrow, small, [sum(c * m[i] for c, m in zip([200, 300, 400], msgs)) % t for i in range(4)])
+    small = pkg.Commitment.linear_combine(narrow, coms, [200, 300, 200])
+    assert pkg.verify_opening_with_context(narrow, small, [sum(c * m[i] for c, m in zip([200, 300, 200], msgs)) % t for i in range(4)])
+    # beyond the budget of the 44-bit modulus the call fails loudly (NULL + message) instead of returning a commitment that
+    # cannot be opened; the oracle draws the same line
+    with pytest.raises(pkg.CoreError):
+        pkg.Commitment.linear_combine(narrow, coms, coeffs)
+    assert "noise budget" in pkg._abi.last_error()
+    rc, _ = oracle.lwe_linear_combine(17592186044417, 4096, 2, 3.19, 5, [c.as_words() for c in coms], coeffs)
+    assert rc == -1
     narrow.close()
+    # a context whose fresh commitments could not be opened is refused at creation
+    with pytest.raises(pkg.CoreError):
+        pkg.LweContext(pkg.Params(q=17592186044417, n=4096, k=2, sigma=200.0), key_seed=5)
+
+
+def test_blinding_never_repeats_across_messages_or_contexts(pkg, oracle):
+    """Same seed, different messages / contexts: fresh blinding (round-1 advisor finding, high).  Bit-exact with the oracle's
+    key schedule; same (seed, message, context) still reproduces the commitment."""
+    q, n, k = 17592186044417, 4096, 2
+    a = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xABC)
+    b = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xABD)
+    m1, m2 = [1, 2, 3, 4], [5, 9, 3, 1000]
+    c1, c2 = pkg.Commitment(a, m1, seed=42).as_words(), pkg.Commitment(a, m2, seed=42).as_words()
+    assert np.array_equal(c1, oracle.lwe_commit(q, n, k, 3.19, 0xABC, m1, 42))
+    assert np.array_equal(c2, oracle.lwe_commit(q, n, k, 3.19, 0xABC, m2, 42))
+    u1, u2 = c1[5:5 + k * n], c2[5:5 + k * n]
+    assert np.count_nonzero(u1 == u2) < 8
+    t, qi = a.plain_modulus, a.commit_modulus
+    v1, v2 = c1[5 + k * n:], c2[5 + k * n:]
+    leak = [(int(v1[i]) - int(v2[i]) - (qi // t) * (m1[i] - m2[i])) % qi for i in range(4)]
+    assert all(min(x, qi - x) > 10**6 for x in leak)
+    assert np.array_equal(c1, pkg.Commitment(a, m1, seed=42).as_words())
+    assert np.array_equal(pkg.Commitment(b, m1, seed=42).as_words(), oracle.lwe_commit(q, n, k, 3.19, 0xABD, m1, 42))
+    # batch path: every row gets its own message-bound key
+    msgs = np.array([m1, m2, m1], dtype=np.uint64)
+    rows = pkg.Commitment.batch_words(a, msgs, np.array([42, 42, 42], dtype=np.uint64))
+    assert np.array_equal(rows[0], c1) and np.array_equal(rows[1], c2) and np.array_equal(rows[2], c1)
+    a.close(); b.close()
+
+
+def test_verify_compares_raw_message_words(pkg, lib, ctx):
+    """commitment.cpp:223-226: decoded[i] ^ message[i] on the words as given — a claimed word >= t never opens."""
+    t = ctx.plain_modulus
+    msg = np.array([1, 2, 3, 4], dtype=np.uint64)
+    comm = lib.lwe_commit(ctx.handle, msg.ctypes.data, 4, 77)
+    assert lib.lwe_verify_opening(ctx.handle, comm, msg.ctypes.data, 4, None) == 1
+    shifted = msg.copy(); shifted[0] += np.uint64(t)
+    assert lib.lwe_verify_opening(ctx.handle, comm, shifted.ctypes.data, 4, None) == 0
+    res = np.zeros(2, dtype=np.int32)
+    both = np.stack([msg, shifted])
+    arr = (ctypes.POINTER(pkg._abi.LweCommitment) * 2)(comm, comm)
+    assert lib.lwe_verify_opening_batch(ctx.handle, arr, both.ctypes.data, 4, 2, res.ctypes.data) == 0
+    assert list(res) == [1, 0]
+    # the commit side embeds m mod t: the same commitment under the same seed
+    again = lib.lwe_commit(ctx.handle, shifted.ctypes.data, 4, 77)
+    assert np.array_equal(words(comm), words(again))
+    lib.lwe_commitment_free(comm); lib.lwe_commitment_free(again)
 
 
 @pytest.mark.parametrize("row_words,n_inputs", [(1, 0), (5, 2), (13, 0), (14, 1), (15, 3), (16, 0), (30, 17), (31, 40), (300, 3), (12293, 2)])

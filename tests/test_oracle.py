@@ -225,6 +225,65 @@ def test_linear_combination(oracle):
     assert oracle.lwe_verify(comm_words=comb, msg=expected, **P) == 0
 
 
+def test_blinding_never_repeats_across_messages_or_contexts(oracle):
+    """Round-1 advisor finding (high): with the stream key derived from `seed` alone, two commitments under one seed shared
+    u = A^T r + e1 and v1 - v2 = Delta (m1 - m2) leaked the message difference.  The per-commitment key is now
+    PRF(seed, context id, embedded message): same (seed, message, context) -> same commitment; anything else -> fresh blinding."""
+    q, n, k, t = Q44, 256, 2, oracle.L.oracle_largest_prime_1mod(512, 20)
+    m1, m2 = [1, 2, 3, 4], [5, 9, 3, 1000]
+    c1 = oracle.lwe_commit(q, n, k, 3.19, 0xABC, m1, 42)
+    c2 = oracle.lwe_commit(q, n, k, 3.19, 0xABC, m2, 42)
+    u1, u2 = c1[5:5 + k * n], c2[5:5 + k * n]
+    assert np.count_nonzero(u1 == u2) < 8                                   # not the shared u of the old scheme
+    delta = q // t
+    v1, v2 = c1[5 + k * n:], c2[5 + k * n:]
+    leak = [(int(v1[i]) - int(v2[i]) - delta * (m1[i] - m2[i])) % q for i in range(4)]
+    assert all(min(x, q - x) > 10**6 for x in leak)                         # v1 - v2 is not Delta (m1 - m2) + small noise any more
+    assert np.array_equal(c1, oracle.lwe_commit(q, n, k, 3.19, 0xABC, m1, 42))          # still deterministic
+    assert np.array_equal(c1, oracle.lwe_commit(q, n, k, 3.19, 0xABC, m1 + [0, 0], 42))  # same embedded plaintext
+    # the key itself: depends on seed, context id and the message mod t only
+    _, _, id_a = oracle.context_keys(0xABC)
+    _, _, id_b = oracle.context_keys(0xABD)
+    key = oracle.commit_key(42, id_a, m1, t)
+    assert np.array_equal(key, oracle.commit_key(42, id_a, [m1[0] + t] + m1[1:], t))
+    for other in (oracle.commit_key(43, id_a, m1, t), oracle.commit_key(42, id_b, m1, t), oracle.commit_key(42, id_a, m2, t),
+                  oracle.commit_key(42, id_a, m1[::-1], t), oracle.commit_key(42, id_a, m1 + [1], t)):
+        assert not np.array_equal(key, other)
+    pub, sec, _ = oracle.context_keys(0xABC)
+    assert not np.array_equal(pub, sec)                                      # A does not come from the secret key
+
+
+def test_verify_compares_raw_message_words(oracle):
+    """commitment.cpp:223-226 compares decoded[i] with message[i] as given: a claimed word >= t never opens, even when it is
+    congruent to the committed one (round-1 advisor finding: the reduction mod t on the verify side lost binding silently)."""
+    q, n, k = 12289, 256, 2
+    t = oracle.L.oracle_lwe_t(oracle.lwe_handle(q, n, k, 3.19, 7))
+    c = oracle.lwe_commit(q, n, k, 3.19, 7, [1, 2, 3, 4], 9)
+    assert oracle.lwe_verify(q, n, k, 3.19, 7, c, [1, 2, 3, 4]) == 1
+    assert oracle.lwe_verify(q, n, k, 3.19, 7, c, [1 + t, 2, 3, 4]) == 0
+    # the commit side embeds m mod t (the reference encodes out-of-range words unchecked, SURVEY.md §3.2): the commitment to
+    # [1 + t, ...] IS the commitment to [1, ...] and opens only to the canonical words
+    assert np.array_equal(oracle.lwe_commit(q, n, k, 3.19, 7, [1 + t, 2, 3, 4], 9), c)
+
+
+def test_noise_budget_is_enforced(oracle):
+    """Contexts whose fresh commitments could fail to open are refused, and so are combinations whose coefficients exceed the
+    budget (round-1 advisor / verdict: no commitment that silently cannot be opened).  A 60-bit modulus has the reference's range."""
+    assert oracle.L.oracle_lwe_create(Q44, 4096, 2, 200.0, 3) is None       # sigma^2 sqrt(2kn) 8 > Delta / 2 at 44 bits
+    assert oracle.L.oracle_lwe_create(Q44, 4096, 2, 3.19, 3)
+    q, n, k = Q44, 256, 2
+    t = oracle.L.oracle_lwe_t(oracle.lwe_handle(q, n, k, 3.19, 5))
+    cs = [oracle.lwe_commit(q, n, k, 3.19, 5, m, 10 + i) for i, m in enumerate([[1, 2], [3, 4]])]
+    rc, out = oracle.lwe_linear_combine(q, n, k, 3.19, 5, cs, [700, 800])
+    assert rc == 0 and oracle.lwe_verify(q, n, k, 3.19, 5, out, [(700 * 1 + 800 * 3) % t, (700 * 2 + 800 * 4) % t]) == 1
+    rc, _ = oracle.lwe_linear_combine(q, n, k, 3.19, 5, cs, [t - 1, 5])
+    assert rc == -1
+    big = 1152921504606584833                                                # 60-bit prime = 1 (mod 2^18)
+    cs = [oracle.lwe_commit(big, n, k, 3.19, 5, m, 10 + i) for i, m in enumerate([[1, 2], [3, 4]])]
+    rc, out = oracle.lwe_linear_combine(big, n, k, 3.19, 5, cs, [t - 1, t - 2])
+    assert rc == 0 and oracle.lwe_verify(big, n, k, 3.19, 5, out, [((t - 1) * 1 + (t - 2) * 3) % t, ((t - 1) * 2 + (t - 2) * 4) % t]) == 1
+
+
 def test_commit_truncates_and_pads(oracle):
     small = dict(q=12289, n=64, k=1, sigma=3.19, key_seed=5)
     long_msg = list(range(1, 101))

@@ -342,7 +342,18 @@ def test_batched_prove_chain_matches_the_one_by_one_replay(pkg, lib, oracle):
     W = rows.shape[1]
     assert lib.lsr_fs_challenge_batch_flat(publics.ctypes.data, n_public, rows.ctypes.data, W, batch, Q, alphas.ctypes.data, ha.ctypes.data, 0) == 0
     assert lib.lsr_fs_challenge_batch_flat(alphas.ctypes.data, 1, rows.ctypes.data, W, batch, Q, betas.ctypes.data, hb.ctypes.data, 0) == 0
-    assert pkg.verify_openings_words(ctx, rows, msgs) == [1] * batch
+    # Field coefficients are wider than the plaintext modulus: they are embedded mod t and — exactly as with the reference's
+    # decode-and-compare (commitment.cpp:223-226) — open to their residues, never to the wide words themselves.
+    t = np.uint64(ctx.plain_modulus)
+    assert pkg.verify_openings_words(ctx, rows, msgs % t) == [1] * batch
+    assert pkg.verify_openings_words(ctx, rows, msgs) == [int(bool((msgs[i] < t).all())) for i in range(batch)]
+    # full binding of the wide coefficients: commit to their 16-bit limbs (lsr_words_to_limbs)
+    limbs = pkg.words_to_limbs(msgs).reshape(batch, -1)
+    assert limbs.shape[1] == 4 * msgs.shape[1] and int(limbs.max()) < 2**16
+    limb_rows = pkg.Commitment.batch_words(ctx, limbs, seeds)
+    assert pkg.verify_openings_words(ctx, limb_rows, limbs) == [1] * batch
+    tampered = msgs.copy(); tampered[0, 0] ^= np.uint64(1 << 40)          # a change the residue mod t might miss
+    assert pkg.verify_openings_words(ctx, limb_rows[:1], pkg.words_to_limbs(tampered[:1]).reshape(1, -1)) == [0]
     # --- one proof at a time ---
     for i in range(batch):
         ea, eb, ec = (oracle.sparse_mul_vec(mat, m, ws[i], Q) for mat in (a, b, c))

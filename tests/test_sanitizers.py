@@ -26,5 +26,5 @@ def test_library_host_code_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "host_san")
     csrc = os.path.join(ROOT, "lambda-snark-r_amd/csrc")
     run(["g++", "-std=c++17", *SAN, "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(ROOT, "tests/c/host_sanitizer_driver.cpp"),
-         os.path.join(csrc, "lsr_host_math.cpp"), os.path.join(csrc, "lsr_transcript.cpp"), "-o", exe])
+         os.path.join(csrc, "lsr_host_math.cpp"), os.path.join(csrc, "lsr_keys.cpp"), os.path.join(csrc, "lsr_transcript.cpp"), "-o", exe])
     assert "ok" in run([exe], env=ENV)
