@@ -132,6 +132,34 @@ int lsr_lwe_sample_blinding_device(const LweContext* ctx, uint64_t* d_e1, size_t
 int lsr_fill_splitmix_device(uint64_t* d_out, size_t objects, size_t len, uint64_t seed_base, uint64_t q,
                              void* stream) LSR_NOEXCEPT;
 
+/* ---------------- several devices of one node inside ONE call (BASELINE config 4) ----------------
+ * Independent polynomials / commitments: the batch is cut into `shards` contiguous slices (lsr_shard_bounds: sizes differ
+ * by at most one, earlier shards take the extra), shard g is driven by ctxs[g] on ITS device from its own host thread and
+ * stream, and every slice of the result is copied device -> host straight into its place in the caller's single array
+ * (allocate it with lsr_host_alloc_pinned for full PCIe speed).  No collective, no device-to-device traffic; the shared
+ * resource is host PCIe / DRAM bandwidth.  The reference has no counterpart (single-threaded CPU library; its only
+ * concurrency statement is `unsafe impl Send`, rust-api/lambda-snark/src/context.rs:76).  The contexts of a call must be
+ * distinct objects; several may live on the same device (that is how a one-GPU box exercises this path). */
+void  lsr_shard_bounds(size_t batch, int shards, int index, size_t* first, size_t* count) LSR_NOEXCEPT;
+void* lsr_host_alloc_pinned(size_t bytes) LSR_NOEXCEPT;     /* NULL on failure */
+void  lsr_host_free_pinned(void* p) LSR_NOEXCEPT;
+/* the same commitment context (same keys: same A_hat, s, b_hat, context id) on another device; commitments made by either
+ * replica verify and combine under the other.  NULL on failure. */
+LweContext* lsr_lwe_context_replicate(const LweContext* ctx, int device) LSR_NOEXCEPT;
+/* ntt_forward_batch / ntt_inverse_batch over `shards` contexts of the same (q, n): polys is ONE host array [batch][n] */
+int lsr_ntt_forward_batch_sharded(const NttContext* const* ctxs, int shards, uint64_t* polys, size_t batch) LSR_NOEXCEPT;
+int lsr_ntt_inverse_batch_sharded(const NttContext* const* ctxs, int shards, uint64_t* polys, size_t batch) LSR_NOEXCEPT;
+/* lsr_lwe_commit_batch_flat over replicas of one context: host messages [batch][msg_len], seeds [batch] (or NULL), rows
+ * written to out_words[batch][lsr_lwe_commitment_words] — bit-identical to the one-device call. */
+int lsr_lwe_commit_batch_flat_sharded(LweContext* const* ctxs, int shards, const uint64_t* messages, size_t msg_len,
+                                      size_t batch, const uint64_t* seeds, uint64_t* out_words) LSR_NOEXCEPT;
+/* The config-4 workload: u_j = INTT(A_hat^T NTT(r_j)) + e1_j with DEVICE-resident inputs per shard and a HOST gather.
+ * d_r[g], d_e1[g]: arrays on ctxs[g]'s device holding rows [first_g, first_g + count_g) of the batch ([count_g][k][n]);
+ * host_u: one array [batch][k][n].  seconds (optional, 2 doubles): [0] slowest shard's compute time, [1] slowest shard's
+ * device -> host gather time.  0 / -1. */
+int lsr_mlwe_matvec_batch_sharded(LweContext* const* ctxs, int shards, uint64_t* const* d_r, const uint64_t* const* d_e1,
+                                  size_t batch, uint64_t* host_u, double* seconds) LSR_NOEXCEPT;
+
 /* ---------------- Fiat–Shamir consumer of the commitment words (host, no GPU needed) ---------------- */
 /* The transcript of rust-api/lambda-snark/src/challenge.rs:102-134: SHA3-256 over "LAMBDA-SNARK-R-FS-v1", the
  * public inputs and ALL commitment words (each length-prefixed, little-endian); alpha = LE64(h[0..8]) mod modulus.

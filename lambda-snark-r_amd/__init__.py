@@ -176,12 +176,90 @@ class LweContext:
             raise CoreError("lsr_lwe_public_matrix failed")
         return a
 
+    def replicate(self, device=-1):
+        """``lsr_lwe_context_replicate``: the same context (same keys) on another device, for sharded runs."""
+        twin = object.__new__(LweContext)
+        twin._lib, twin.params = self._lib, self.params
+        twin._h = self._lib.lsr_lwe_context_replicate(self._h, device)
+        if not twin._h:
+            raise CoreError("FfiError: lsr_lwe_context_replicate returned NULL")
+        return twin
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.lwe_context_free(self._h)
             self._h = None
 
     __del__ = close
+
+
+class PinnedArray:
+    """A uint64 host array in page-locked memory (``lsr_host_alloc_pinned``): the single gather target of a sharded call."""
+
+    def __init__(self, shape):
+        self._lib = _abi.lib()
+        self.shape = tuple(int(x) for x in shape)
+        count = int(np.prod(self.shape))
+        self._p = self._lib.lsr_host_alloc_pinned(max(count, 1) * 8)
+        if not self._p:
+            raise MemoryError("lsr_host_alloc_pinned failed")
+        self.array = np.ctypeslib.as_array(ctypes.cast(self._p, ctypes.POINTER(ctypes.c_uint64)), shape=(count,)).reshape(self.shape)
+
+    @property
+    def ptr(self):
+        return self._p
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._lib.lsr_host_free_pinned(self._p)
+            self._p = None
+
+    __del__ = close
+
+
+def shard_bounds(batch, shards, index):
+    """``lsr_shard_bounds`` -> (first, count) of shard `index`."""
+    first, count = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _abi.lib().lsr_shard_bounds(batch, shards, index, ctypes.byref(first), ctypes.byref(count))
+    return first.value, count.value
+
+
+def _handles(ctxs):
+    return (ctypes.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+
+
+def sharded_ntt(ctxs, polys, inverse=False):
+    """``lsr_ntt_forward_batch_sharded`` / ``_inverse_``: `polys` is ONE host array [batch][n], transformed in place."""
+    lib = _abi.lib()
+    fn = lib.lsr_ntt_inverse_batch_sharded if inverse else lib.lsr_ntt_forward_batch_sharded
+    if fn(_handles(ctxs), len(ctxs), polys.ctypes.data, polys.shape[0]) != 0:
+        raise CoreError("sharded transform failed: " + _abi.last_error())
+    return polys
+
+
+def sharded_commit_words(ctxs, messages, seeds, out=None):
+    """``lsr_lwe_commit_batch_flat_sharded``: rows [batch][words] written into `out` (a host array, e.g. ``PinnedArray.array``)."""
+    lib = _abi.lib()
+    msgs = _u64_array(messages, "messages")
+    sd = _u64_array(seeds, "seeds")
+    if out is None:
+        out = np.zeros((msgs.shape[0], lib.lsr_lwe_commitment_words(ctxs[0].handle)), dtype=np.uint64)
+    if lib.lsr_lwe_commit_batch_flat_sharded(_handles(ctxs), len(ctxs), msgs.ctypes.data, msgs.shape[1], msgs.shape[0], sd.ctypes.data, out.ctypes.data) != 0:
+        raise CoreError("CommitmentFailed: " + _abi.last_error())
+    return out
+
+
+def sharded_matvec(ctxs, d_r_ptrs, d_e1_ptrs, batch, host_u):
+    """``lsr_mlwe_matvec_batch_sharded``: device-resident inputs per shard, gather into the host array `host_u`;
+    returns (slowest shard's compute seconds, slowest shard's gather seconds)."""
+    lib = _abi.lib()
+    r = (ctypes.c_void_p * len(ctxs))(*d_r_ptrs)
+    e = (ctypes.c_void_p * len(ctxs))(*d_e1_ptrs)
+    seconds = (ctypes.c_double * 2)()
+    if lib.lsr_mlwe_matvec_batch_sharded(_handles(ctxs), len(ctxs), r, e, batch, host_u.ctypes.data, seconds) != 0:
+        raise CoreError("sharded matvec failed: " + _abi.last_error())
+    return seconds[0], seconds[1]
 
 
 class Commitment:

@@ -108,6 +108,14 @@ SIGNATURES = {
     "lsr_lwe_verify_opening_batch_flat": (c_int, [vp, vp, vp, c_size, c_size, vp]),
     "lsr_mlwe_matvec_batch_device": (c_int, [vp, vp, vp, vp, c_size, vp, vp]),
     "lsr_lwe_sample_blinding_device": (c_int, [vp, vp, c_size, vp, vp]),
+    "lsr_shard_bounds": (None, [c_size, c_int, c_int, vp, vp]),
+    "lsr_host_alloc_pinned": (vp, [c_size]),
+    "lsr_host_free_pinned": (None, [vp]),
+    "lsr_lwe_context_replicate": (vp, [vp, c_int]),
+    "lsr_ntt_forward_batch_sharded": (c_int, [vp, c_int, vp, c_size]),
+    "lsr_ntt_inverse_batch_sharded": (c_int, [vp, c_int, vp, c_size]),
+    "lsr_lwe_commit_batch_flat_sharded": (c_int, [vp, c_int, vp, c_size, c_size, vp, vp]),
+    "lsr_mlwe_matvec_batch_sharded": (c_int, [vp, c_int, vp, vp, c_size, vp, vp]),
     "lsr_words_to_limbs": (c_size, [vp, c_size, ctypes.c_uint, ctypes.c_uint, vp]),
     "lsr_fill_splitmix_device": (c_int, [vp, c_size, c_size, u64, u64, vp]),
     "lsr_fs_challenge": (c_int, [vp, c_size, ctypes.POINTER(LweCommitment), u64, vp, vp]),

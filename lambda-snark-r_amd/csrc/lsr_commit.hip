@@ -13,6 +13,7 @@
 //   combine : sum_i (c_i mod t) (u_i, v_i)
 // Wire format: data[0] = payload bytes; payload = {"LSRC0001", n | k<<32, q, t, u[k][n], v[n]}.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -339,7 +340,7 @@ static bool fused_eligible(const LweContext& c) {
     return c.ntt->use_f64 && (c.logn == 16 || c.logn == 17) && c.k >= 1 && c.k <= 4;
 }
 
-static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_seed, int device) {
+static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_seed, int device, const ContextKeys* replicate = nullptr) {
     if (!params) return nullptr;                                   // commitment.cpp:103
     uint32_t k = params->module_rank ? params->module_rank : 1;
     const uint32_t n = params->ring_degree;
@@ -381,7 +382,7 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
         c->cdf.upload(table);
         c->cdf_entries = static_cast<uint32_t>(table.size());
         c->key_seed = key_seed;
-        c->keys = derive_context_keys(key_seed);
+        c->keys = replicate ? *replicate : derive_context_keys(key_seed);
         const size_t kn = (size_t)k * n;
         c->a_hat.allocate((size_t)k * kn);
         c->s_hat.allocate(kn);
@@ -913,6 +914,49 @@ static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** 
 
 }  // namespace lsr
 
+// one host thread per shard; body(g, first, count) runs with the shard's device current
+template <class F>
+static int run_shards(const char* where, int shards, size_t batch, LweContext* const* ctxs, F&& body) noexcept {
+    std::vector<int> rc(shards, 0);
+    std::vector<std::string> errors(shards);
+    std::vector<std::thread> pool;
+    for (int g = 0; g < shards; ++g)
+        pool.emplace_back([&, g] {
+            size_t first = 0, count = 0;
+            lsr_shard_bounds(batch, shards, g, &first, &count);
+            if (count == 0) return;
+            try {
+                lsr::DeviceGuard guard(ctxs[g]->device);
+                body(g, first, count);
+            } catch (const std::exception& e) {
+                rc[g] = -1;
+                errors[g] = e.what();
+            } catch (...) {
+                rc[g] = -1;
+            }
+        });
+    for (std::thread& th : pool) th.join();
+    for (int g = 0; g < shards; ++g)
+        if (rc[g] != 0) {
+            lsr::set_last_error(std::string(where) + ": shard " + std::to_string(g) + ": " + errors[g]);
+            std::fprintf(stderr, "lambda_snark_core: %s failed on shard %d: %s\n", where, g, errors[g].c_str());
+            return -1;
+        }
+    return 0;
+}
+
+static bool shards_compatible(LweContext* const* ctxs, int shards) {
+    if (!ctxs || shards <= 0) return false;
+    for (int g = 0; g < shards; ++g) {
+        if (!ctxs[g]) return false;
+        if (ctxs[g]->q != ctxs[0]->q || ctxs[g]->n != ctxs[0]->n || ctxs[g]->k != ctxs[0]->k || ctxs[g]->t != ctxs[0]->t) return false;
+        if (std::memcmp(ctxs[g]->keys.id, ctxs[0]->keys.id, sizeof ctxs[0]->keys.id) != 0) return false;   // replicas of ONE context
+        for (int h = 0; h < g; ++h)
+            if (ctxs[h] == ctxs[g]) return false;    // a context serialises its callers: one per shard
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
@@ -1121,6 +1165,59 @@ size_t lsr_words_to_limbs(const uint64_t* words, size_t count, unsigned limb_bit
             limbs[i * limbs_per_word + l] = shift < 64 ? (words[i] >> shift) & mask : 0;
         }
     return count * limbs_per_word;
+}
+
+LweContext* lsr_lwe_context_replicate(const LweContext* ctx, int device) noexcept {
+    if (!ctx) return nullptr;
+    try {
+        return lsr::create_lwe_context(&ctx->params, ctx->key_seed, device, &ctx->keys);   // same keys => same A_hat, s, b_hat
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "lwe_context_create error: %s\n", e.what());
+        return nullptr;
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+int lsr_lwe_commit_batch_flat_sharded(LweContext* const* ctxs, int shards, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds,
+                                      uint64_t* out_words) noexcept {
+    if (!shards_compatible(ctxs, shards) || !messages || !out_words) return -1;
+    if (batch == 0) return 0;
+    const size_t words = lsr::kHeaderWords + ((size_t)ctxs[0]->k + 1) * ctxs[0]->n;
+    return run_shards("lsr_lwe_commit_batch_flat_sharded", shards, batch, ctxs, [&](int g, size_t first, size_t count) {
+        if (lsr_lwe_commit_batch_flat(ctxs[g], messages + first * msg_len, msg_len, count, seeds ? seeds + first : nullptr, out_words + first * words) != 0)
+            throw std::runtime_error(lsr::last_error_cstr());
+    });
+}
+
+int lsr_mlwe_matvec_batch_sharded(LweContext* const* ctxs, int shards, uint64_t* const* d_r, const uint64_t* const* d_e1, size_t batch, uint64_t* host_u,
+                                  double* seconds) noexcept {
+    if (!shards_compatible(ctxs, shards) || !d_r || !d_e1 || !host_u) return -1;
+    if (batch == 0) return 0;
+    const size_t vec_words = (size_t)ctxs[0]->k * ctxs[0]->n;
+    std::vector<double> compute(shards, 0.0), gather(shards, 0.0);
+    const int rc = run_shards("lsr_mlwe_matvec_batch_sharded", shards, batch, ctxs, [&](int g, size_t first, size_t count) {
+        if (!d_r[g] || !d_e1[g]) throw std::runtime_error("NULL device array for a non-empty shard");
+        const LweContext& c = *ctxs[g];
+        std::lock_guard<std::mutex> lock(c.mutex);
+        lsr::DeviceBuffer<uint64_t> d_u(count * vec_words);
+        hipStream_t s = c.ntt->stream;
+        const auto t0 = std::chrono::steady_clock::now();
+        lsr::mlwe_matvec_device(c, d_r[g], d_e1[g], d_u.ptr, count, s, true);
+        LSR_HIP(hipStreamSynchronize(s));
+        const auto t1 = std::chrono::steady_clock::now();
+        // the gather: this shard's slice goes straight into its place in the caller's single (ideally pinned) array
+        LSR_HIP(hipMemcpyAsync(host_u + first * vec_words, d_u.ptr, count * vec_words * 8, hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipStreamSynchronize(s));
+        const auto t2 = std::chrono::steady_clock::now();
+        compute[g] = std::chrono::duration<double>(t1 - t0).count();
+        gather[g] = std::chrono::duration<double>(t2 - t1).count();
+    });
+    if (seconds) {
+        seconds[0] = *std::max_element(compute.begin(), compute.end());
+        seconds[1] = *std::max_element(gather.begin(), gather.end());
+    }
+    return rc;
 }
 
 int lsr_lwe_sample_blinding_device(const LweContext* ctx, uint64_t* d_e1, size_t batch, const uint64_t* seeds, void* stream) noexcept {

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <type_traits>
 
 #include "lambda_snark/batch.h"
@@ -522,6 +523,65 @@ int lsr_ntt_mul_pointwise_device(const NttContext* ctx, uint64_t* d_result, cons
         lsr::DeviceGuard guard(ctx->device);
         lsr::launch_pointwise(*ctx, d_result, d_a, d_b, count, static_cast<hipStream_t>(stream));
     });
+}
+
+/* ---- multi-device sharding: contiguous slices, one host thread per shard, no collective ---- */
+void lsr_shard_bounds(size_t batch, int shards, int index, size_t* first, size_t* count) noexcept {
+    size_t lo = 0, len = 0;
+    if (shards > 0 && index >= 0 && index < shards) {
+        const size_t base = batch / (size_t)shards, extra = batch % (size_t)shards;
+        lo = (size_t)index * base + std::min<size_t>((size_t)index, extra);
+        len = base + ((size_t)index < extra ? 1 : 0);
+    }
+    if (first) *first = lo;
+    if (count) *count = len;
+}
+
+void* lsr_host_alloc_pinned(size_t bytes) noexcept {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void lsr_host_free_pinned(void* p) noexcept {
+    if (p) (void)hipHostFree(p);
+}
+
+static int ntt_batch_sharded(const char* where, const NttContext* const* ctxs, int shards, uint64_t* polys, size_t batch, bool inverse) noexcept {
+    if (!ctxs || shards <= 0 || !polys) return -1;
+    for (int g = 0; g < shards; ++g)
+        if (!ctxs[g] || ctxs[g]->degree != ctxs[0]->degree || ctxs[g]->modulus != ctxs[0]->modulus) return -1;
+    if (batch == 0) return 0;
+    std::vector<int> rc(shards, 0);
+    std::vector<std::string> errors(shards);
+    std::vector<std::thread> pool;
+    for (int g = 0; g < shards; ++g)
+        pool.emplace_back([&, g] {
+            size_t first = 0, count = 0;
+            lsr_shard_bounds(batch, shards, g, &first, &count);
+            if (count == 0) return;
+            try {
+                lsr::host_ntt(*ctxs[g], polys + first * ctxs[g]->degree, count, inverse);   // H2D, transform, D2H straight into the caller's array
+            } catch (const std::exception& e) {
+                rc[g] = -1;
+                errors[g] = e.what();
+            } catch (...) {
+                rc[g] = -1;
+            }
+        });
+    for (std::thread& th : pool) th.join();
+    for (int g = 0; g < shards; ++g)
+        if (rc[g] != 0) {
+            set_last_error(std::string(where) + ": shard " + std::to_string(g) + ": " + errors[g]);
+            std::fprintf(stderr, "lambda_snark_core: %s failed on shard %d: %s\n", where, g, errors[g].c_str());
+            return -1;
+        }
+    return 0;
+}
+int lsr_ntt_forward_batch_sharded(const NttContext* const* ctxs, int shards, uint64_t* polys, size_t batch) noexcept {
+    return ntt_batch_sharded("lsr_ntt_forward_batch_sharded", ctxs, shards, polys, batch, false);
+}
+int lsr_ntt_inverse_batch_sharded(const NttContext* const* ctxs, int shards, uint64_t* polys, size_t batch) noexcept {
+    return ntt_batch_sharded("lsr_ntt_inverse_batch_sharded", ctxs, shards, polys, batch, true);
 }
 
 uint64_t lsr_minimal_primitive_root(uint64_t q, uint32_t n) noexcept {

@@ -1,8 +1,11 @@
 """Multi-GPU layout of the hot path: independent polynomials / commitments shard across the GPUs of one node
 with NO data-path collective; per-GPU results are gathered on the host.
 
-One process per GPU (rank r drives device LOCAL_RANK).  ``torch.distributed`` is used only as plumbing:
-the gather moves host arrays (gloo or nccl-with-host-objects both work), never device buffers over xGMI.
+Two forms.  (1) Inside ONE process: the library's own sharder (``lsr_*_sharded`` in include/lambda_snark/batch.h; Python:
+``sharded_ntt``, ``sharded_commit_words``, ``sharded_matvec``) — one host thread and stream per device, slices copied
+device -> host straight into one pinned array.  (2) One process per GPU (rank r drives device LOCAL_RANK), as `bench.py` is
+launched: this module.  ``torch.distributed`` is plumbing only — the gather moves host rows as raw tensors over gloo, never
+device buffers over xGMI, and nothing on the data path is a collective.
 """
 import numpy as np
 
@@ -17,17 +20,36 @@ def shard_bounds(batch, world_size, rank):
 
 
 def gather_batches(local, dst=0, group=None):
-    """Gather per-rank [local_batch, ...] host arrays into one array on `dst` (None elsewhere), in rank order."""
+    """Gather per-rank [local_batch, ...] host arrays into ONE preallocated array on `dst` (None elsewhere), in rank order.
+    The rows travel as raw tensor bytes (``dist.gather`` of int64 views, no pickling); the slice sizes follow from
+    ``shard_bounds`` of the summed batch, so no size exchange is needed beyond one small all_gather."""
+    import torch
     import torch.distributed as dist
+    local = np.ascontiguousarray(local)
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return np.ascontiguousarray(local)
+        return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    parts = [None] * world if rank == dst else None
-    dist.gather_object(np.ascontiguousarray(local), parts, dst=dst, group=group)
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64), group=group)
+    counts = [int(c.item()) for c in counts]
+    row_shape = local.shape[1:]
+    row_bytes = (int(np.prod(row_shape)) if row_shape else 1) * local.dtype.itemsize
+    pad = max(counts)                                    # dist.gather wants equal shapes: pad to the largest slice (<= 1 row more)
+    send = torch.zeros((pad, row_bytes), dtype=torch.uint8)
+    if local.shape[0]:
+        send[: local.shape[0]] = torch.from_numpy(local.reshape(local.shape[0], -1).view(np.uint8).reshape(local.shape[0], row_bytes))
+    parts = [torch.empty((pad, row_bytes), dtype=torch.uint8) for _ in range(world)] if rank == dst else None
+    dist.gather(send, parts, dst=dst, group=group)
     if rank != dst:
         return None
-    parts = [p for p in parts if p.shape[0] > 0]
-    return np.concatenate(parts, axis=0) if parts else np.ascontiguousarray(local)[:0]
+    out = np.empty((sum(counts),) + tuple(row_shape), dtype=local.dtype)
+    flat = out.reshape(out.shape[0], -1).view(np.uint8).reshape(out.shape[0], row_bytes) if out.shape[0] else None
+    at = 0
+    for c, p in zip(counts, parts):
+        if c:
+            flat[at:at + c] = p[:c].numpy()
+            at += c
+    return out
 
 
 def sharded_transform(polys, transform, group=None, dst=0):

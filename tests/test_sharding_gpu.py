@@ -1,0 +1,139 @@
+"""The in-library multi-device path (BASELINE config 4) on the devices that are visible.  The test box has
+ONE GPU, so the shards are distinct contexts on the same device — that exercises the slicing, the per-shard host threads
+and streams, the replicated keys and the gather into one host array; a node with more GPUs only changes the device index.
+No scaling curve has been measured on hardware (no multi-GPU node was available to the builder)."""
+import ctypes
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Q16 = 17592182243329
+
+
+def devices(lib, shards):
+    count = lib.lsr_device_count()
+    return [g % count for g in range(shards)]
+
+
+@pytest.mark.parametrize("shards,batch", [(1, 5), (2, 7), (3, 2), (4, 9)])
+def test_sharded_ntt_equals_oracle(pkg, lib, oracle, shards, batch):
+    q, n = 17592169062401, 4096
+    ctxs = [pkg.NttContext(q, n, device=d) for d in devices(lib, shards)]
+    pinned = pkg.PinnedArray((batch, n))
+    host = oracle.splitmix(0x5EED, q, batch * n).reshape(batch, n)
+    pinned.array[:] = host
+    pkg.sharded_ntt(ctxs, pinned.array)
+    assert np.array_equal(pinned.array, oracle.ntt_forward(q, n, host))
+    pkg.sharded_ntt(ctxs, pinned.array, inverse=True)
+    assert np.array_equal(pinned.array, host)
+    spans = [pkg.shard_bounds(batch, shards, g) for g in range(shards)]
+    assert spans[0][0] == 0 and sum(c for _, c in spans) == batch and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(shards - 1))
+    pinned.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_replicated_contexts_commit_identically(pkg, lib, oracle):
+    """Replicas share every key: rows from a sharded call equal the one-device call word for word, for seeded AND for
+    fresh-entropy contexts, and verify under either replica."""
+    q, n, k = 17592186044417, 4096, 2
+    for key_seed in (0xFEED, 0):                       # 0 = fresh 256-bit keys, copied to the replica
+        main = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=key_seed, device=0)
+        twins = [main] + [main.replicate(d) for d in devices(lib, 3)[1:]]
+        assert all(np.array_equal(t.public_matrix(), main.public_matrix()) for t in twins)
+        rng = np.random.default_rng(5)
+        msgs = rng.integers(0, 1000, size=(11, 6), dtype=np.uint64)
+        seeds = np.arange(1, 12, dtype=np.uint64)
+        single = pkg.Commitment.batch_words(main, msgs, seeds)
+        pinned = pkg.PinnedArray(single.shape)
+        pkg.sharded_commit_words(twins, msgs, seeds, out=pinned.array)
+        assert np.array_equal(pinned.array, single)
+        if key_seed:
+            assert np.array_equal(single[3], oracle.lwe_commit(q, n, k, 3.19, key_seed, msgs[3], int(seeds[3])))
+        assert pkg.verify_openings_words(twins[-1], pinned.array, msgs) == [1] * 11
+        # the same context object twice is refused (a context serialises its callers)
+        with pytest.raises(pkg.CoreError):
+            pkg.sharded_commit_words([main, main], msgs, seeds)
+        pinned.close()
+        for t in twins:
+            t.close()
+
+
+def test_config4_sharded_matvec_gathers_on_the_host(pkg, lib, oracle):
+    """Config 4 shape: rank 4, n = 2^16, the batch cut into contiguous slices, device-resident inputs per shard, one host
+    array out.  Bit-exact against the unsharded call and, for sampled vectors, the oracle."""
+    import torch
+    q, n, k, batch, shards = Q16, 65536, 4, 10, 3
+    main = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xC0DE, device=0)
+    twins = [main] + [main.replicate(d) for d in devices(lib, shards)[1:]]
+    r = np.stack([oracle.splitmix(0xC0FFEE + j, q, k * n).reshape(k, n) for j in range(batch)])
+    seeds = np.arange(1, batch + 1, dtype=np.uint64) * np.uint64(0x9E3779B9)
+    e1 = np.stack([np.stack([oracle.sample_gaussian_seeded(n, 3.19, int(seeds[j]), 5, i) for i in range(k)]) for j in range(batch)])
+    e1 = np.where(e1 < 0, e1 + q, e1).astype(np.uint64)
+    parts_r, parts_e = [], []
+    for g in range(shards):
+        first, count = pkg.shard_bounds(batch, shards, g)
+        dev = torch.device("cuda", lib.lsr_ntt_context_device(lib.lsr_lwe_ntt_context(twins[g].handle)))
+        parts_r.append(torch.from_numpy(r[first:first + count].view(np.int64)).to(dev))
+        parts_e.append(torch.from_numpy(e1[first:first + count].view(np.int64)).to(dev))
+    torch.cuda.synchronize()
+    pinned = pkg.PinnedArray((batch, k, n))
+    compute_s, gather_s = pkg.sharded_matvec(twins, [p.data_ptr() for p in parts_r], [p.data_ptr() for p in parts_e], batch, pinned.array)
+    assert compute_s > 0 and gather_s > 0
+    d_r = torch.from_numpy(r.view(np.int64)).cuda()
+    d_e = torch.from_numpy(e1.view(np.int64)).cuda()
+    d_u = torch.empty_like(d_r)
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.lsr_mlwe_matvec_batch_device(main.handle, d_r.data_ptr(), d_e.data_ptr(), d_u.data_ptr(), batch, None, s) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(pinned.array, d_u.cpu().numpy().view(np.uint64))
+    a_hat = main.public_matrix()
+    for j in (0, 3, 4, 9):                             # first / last of a shard
+        assert np.array_equal(pinned.array[j], oracle.mlwe_matvec(q, n, k, a_hat, r[j], e1[j]))
+    pinned.close()
+    for t in twins:
+        t.close()
+
+
+def _rank_worker(rank, world, port, batch, out_path):
+    """One process per rank, device LOCAL_RANK (mod the visible count): the REAL NttContext path, gathered with gloo."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LOCAL_RANK": str(rank)})
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    import oracle_binding
+    pkg = entry.load_package()
+    import importlib
+    sh = importlib.import_module("lambda_snark_r_amd.sharding")
+    orc = oracle_binding.load()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q, n = 17592169062401, 4096
+    ctx = pkg.NttContext(q, n)                            # device = LOCAL_RANK % visible devices (lsr_runtime default_device)
+    polys = orc.splitmix(0xABC, q, batch * n).reshape(batch, n)
+    got = sh.sharded_transform(polys, lambda a: ctx.forward_batch(a.copy()))
+    if rank == 0:
+        np.save(out_path, got)
+    else:
+        assert got is None
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_two_processes_drive_the_gpu_path_and_gather_with_gloo(oracle, tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "gathered.npy")
+    batch = 9
+    mp.spawn(_rank_worker, args=(2, port, batch, out), nprocs=2, join=True)
+    q, n = 17592169062401, 4096
+    polys = oracle.splitmix(0xABC, q, batch * n).reshape(batch, n)
+    assert np.array_equal(np.load(out), oracle.ntt_forward(q, n, polys))
