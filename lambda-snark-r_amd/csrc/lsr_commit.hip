@@ -269,7 +269,7 @@ struct LweContext {
     // fused matrix–vector pipeline (lsr_commit_fused.hpp): lane-major copy of A_hat, per-stream chunk workspaces, side streams
     static constexpr int kMaxSide = 4;
     lsr::DeviceBuffer<double> a_perm;
-    mutable lsr::DeviceBuffer<uint64_t> ws_mid;
+    mutable lsr::DeviceBuffer<uint64_t> ws_mid, ws_e1_slots;
     mutable hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
     mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
     mutable int n_side = 0;
@@ -430,6 +430,8 @@ static void destroy_lwe_context(LweContext* c) {
         c->ws_r.release(); c->ws_e1.release(); c->ws_e2.release(); c->ws_u.release(); c->ws_v.release();
         c->ws_dm.release(); c->ws_keys.release(); c->ws_flag.release();
         c->a_perm.release(); c->ws_mid.release();
+        if (c->ws_e1_slots.ptr) (void)hipMemset(c->ws_e1_slots.ptr, 0, c->ws_e1_slots.count * 8);
+        c->ws_e1_slots.release();
         for (int i = 0; i < c->n_side; ++i) {
             if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
             if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -465,10 +467,14 @@ static void launch_mid(const LweContext& c, const uint64_t* ws, uint64_t* d_u, s
 //   top forward round r -> workspace | 12 forward stages x k, A_hat^T product, 12 inverse stages x k -> u | top inverse round (+ e1)
 // with the chunks dealt round-robin to side streams, so that the FP64-bound middle kernel of one chunk runs beside the
 // HBM-bound outer rounds of its neighbours.  d_r is only read.
-static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s) {
+// d_e1 == NULL && d_keys != NULL: the blinding residues of a chunk are sampled (domain 5, per-vector keys d_keys[batch][4]) into
+// a chunk-sized buffer on the chunk's stream right before its transforms — no [batch][k][n] array of e1 ever exists, and the
+// sampling of one chunk runs beside the transforms of its neighbours.
+static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s,
+                              const uint64_t* d_keys = nullptr) {
     const uint32_t k = c.k;
     const size_t vec_words = (size_t)k << c.logn;
-    const int want = env_int("LAMBDA_SNARK_COMMIT_STREAMS", 3, 1, LweContext::kMaxSide);
+    const int want = env_int("LAMBDA_SNARK_COMMIT_STREAMS", 2, 1, LweContext::kMaxSide);
     const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_CHUNK_MIB", 128, 1, 4096);
     const size_t chunk = std::max<size_t>(1, (chunk_mib << 20) / (vec_words * 8));
     const int streams = static_cast<int>(std::min<size_t>((size_t)want, (batch + chunk - 1) / chunk));
@@ -480,6 +486,8 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
     if (!c.ev_fork) LSR_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
     const size_t slot_words = std::min(chunk, batch) * vec_words;
     if (c.ws_mid.count < slot_words * streams) c.ws_mid.allocate(slot_words * streams);
+    const bool sample = !d_e1 && d_keys;
+    if (sample && c.ws_e1_slots.count < slot_words * streams) c.ws_e1_slots.allocate(slot_words * streams);
     LSR_HIP(hipEventRecord(c.ev_fork, s));
     for (int i = 0; i < streams; ++i) LSR_HIP(hipStreamWaitEvent(c.side[i], c.ev_fork, 0));
     size_t index = 0;
@@ -487,6 +495,12 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
         const size_t now = std::min(chunk, batch - first);
         hipStream_t st = c.side[index % streams];
         uint64_t* const ws = c.ws_mid.ptr + (index % streams) * slot_words;
+        const uint64_t* blind = d_e1 ? d_e1 + first * vec_words : nullptr;
+        if (sample) {
+            uint64_t* const slot = c.ws_e1_slots.ptr + (index % streams) * slot_words;
+            launch_gaussian(GaussianJob{slot, d_keys + 4 * first, 0, k, kDomE1, c.n, now * k, c.q}, c.cdf.ptr, c.cdf_entries, st);
+            blind = slot;
+        }
         launch_top_round_forward(*c.ntt, ws, d_r + first * vec_words, now * k, st);
         switch (k) {
             case 1: launch_mid<1>(c, ws, d_u + first * vec_words, now, st); break;
@@ -494,7 +508,7 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
             case 3: launch_mid<3>(c, ws, d_u + first * vec_words, now, st); break;
             default: launch_mid<4>(c, ws, d_u + first * vec_words, now, st); break;
         }
-        launch_top_round_inverse(*c.ntt, d_u + first * vec_words, now * k, st, d_e1 ? d_e1 + first * vec_words : nullptr);
+        launch_top_round_inverse(*c.ntt, d_u + first * vec_words, now * k, st, blind);
     }
     for (int i = 0; i < streams; ++i) {
         LSR_HIP(hipEventRecord(c.ev_join[i], c.side[i]));
@@ -1255,14 +1269,19 @@ int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uin
             lsr::mlwe_matvec_device(*ctx, d_r, d_e1, d_u, batch, s, true);
             return 0;
         }
-        // e1 sampled on the device from the per-commit seeds (domain 5), then added
-        lsr::ensure_workspace(*ctx, batch);
+        // e1 sampled on the device from the per-vector raw-seed streams (domain 5), then added
         ctx->ws_key_host.resize(batch * 4);
         for (size_t j = 0; j < batch; ++j) lsr::key_words(lsr::expand_seed64(seeds[j]), ctx->ws_key_host.data() + 4 * j);
+        if (ctx->ws_keys.count < batch * 4) ctx->ws_keys.allocate(batch * 4);
         LSR_HIP(hipMemcpyAsync(ctx->ws_keys.ptr, ctx->ws_key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
-        lsr::launch_gaussian(lsr::GaussianJob{ctx->ws_e1.ptr, ctx->ws_keys.ptr, 0, ctx->k, lsr::kDomE1, ctx->n, batch * ctx->k, ctx->q}, ctx->cdf.ptr,
-                             ctx->cdf_entries, s);
-        lsr::mlwe_matvec_device(*ctx, d_r, ctx->ws_e1.ptr, d_u, batch, s, true);
+        if (ctx->a_perm.ptr && lsr::env_int("LAMBDA_SNARK_COMMIT_FUSED", 1, 0, 1)) {
+            lsr::mlwe_matvec_fused(*ctx, d_r, nullptr, d_u, batch, s, ctx->ws_keys.ptr);
+        } else {
+            lsr::ensure_workspace(*ctx, batch);
+            lsr::launch_gaussian(lsr::GaussianJob{ctx->ws_e1.ptr, ctx->ws_keys.ptr, 0, ctx->k, lsr::kDomE1, ctx->n, batch * ctx->k, ctx->q}, ctx->cdf.ptr,
+                                 ctx->cdf_entries, s);
+            lsr::mlwe_matvec_device(*ctx, d_r, ctx->ws_e1.ptr, d_u, batch, s, false);
+        }
         LSR_HIP(hipStreamSynchronize(s));   // seeds is a host array the caller may reuse
         return 0;
     } catch (const std::exception& e) {

@@ -31,6 +31,31 @@
 #ifndef LSR_F8_TOUCH
 #define LSR_F8_TOUCH 1
 #endif
+// Exchange between the rounds of index bits [3,6) and [0,3): 0 = through the LDS tile (+ barrier), 1 = inside the wavefront
+// with __shfl_xor (the compiler picks DPP / ds_bpermute), 2 = inside the wavefront with explicit DPP moves
+// (quad_perm for lane^1, lane^2; row_shl/row_shr:4 under bank masks for lane^4).  The register field swaps places with
+// lane bits 0..2 — an 8 x 8 transpose among 8 neighbouring lanes — so no other lane of the workgroup is involved and the
+// exchange needs neither LDS storage nor a barrier (north_star: "ds_swizzle/ds_permute for the intra-wavefront transpose
+// stages"; measured in profiles/r02_fused_wave_exchange.txt).
+#ifndef LSR_F8_WAVE_XCHG
+#define LSR_F8_WAVE_XCHG 2
+#endif
+// ablation builds for profiling only (results are wrong): bit 0 = no operand loads, bit 1 = no matrix loads, bit 2 = no stores
+#ifndef LSR_F8_ABLATE
+#define LSR_F8_ABLATE 0
+#endif
+// cache policy of the streamed tile operands and results (0 = default, 2 = nt): they pass through the XCD's L2 once, the matrix
+// slice is re-read by every workgroup
+#ifndef LSR_F8_LOAD_AUX
+#define LSR_F8_LOAD_AUX 2
+#endif
+#ifndef LSR_F8_STORE_AUX
+#define LSR_F8_STORE_AUX 2
+#endif
+// matrix loads one component ahead of their products (double-buffered in the registers the round's multipliers vacate)
+#ifndef LSR_F8_MAT_AHEAD
+#define LSR_F8_MAT_AHEAD 1
+#endif
 
 namespace lsr {
 
@@ -52,7 +77,52 @@ __host__ __device__ constexpr uint32_t f8_base(uint32_t t) {
     if (R == 0) return t;
     if (R == 1) return (t & 63u) | ((t >> 6) << 9);
     if (R == 2) return (t & 7u) | ((t >> 3) << 6);
+#if LSR_F8_WAVE_XCHG
+    return ((t & 7u) << 3) | ((t >> 3) << 6);        // lane bits 0..2 carry index bits 3..5 after the in-wavefront transpose
+#else
     return (((t >> 3) & 31u) << 3) | ((t & 7u) << 8) | ((t >> 8) << 11);
+#endif
+}
+
+// value of lane (self ^ M), M in {1, 2, 4}
+template <int M>
+__device__ __forceinline__ double f8_xor_lane(double x) {
+#if LSR_F8_WAVE_XCHG == 2
+    const long long bits = __double_as_longlong(x);
+    int lo = (int)bits, hi = (int)(bits >> 32);
+    if constexpr (M == 1) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);   // quad_perm:[1,0,3,2]
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+    } else if constexpr (M == 2) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
+    } else {
+        const int l0 = lo, h0 = hi;
+        lo = __builtin_amdgcn_update_dpp(l0, l0, 0x104, 0xF, 0x5, false);   // row_shl:4 into banks 0, 2 (lanes with bit 2 clear)
+        lo = __builtin_amdgcn_update_dpp(lo, l0, 0x114, 0xF, 0xA, false);   // row_shr:4 into banks 1, 3
+        hi = __builtin_amdgcn_update_dpp(h0, h0, 0x104, 0xF, 0x5, false);
+        hi = __builtin_amdgcn_update_dpp(hi, h0, 0x114, 0xF, 0xA, false);
+    }
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+#else
+    return __shfl_xor(x, M, 64);
+#endif
+}
+// registers <-> lane bits 0..2: element (lane bit s = a, register bit s = b) moves to (lane bit s = b, register bit s = a)
+__device__ __forceinline__ void f8_transpose_regs_lanes(double (&v)[kF8Regs], uint32_t t) {
+    static_for<0, 3>([&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        constexpr int M = 1 << S;
+        const bool up = (t >> S) & 1u;
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) {
+            if (k & M) continue;
+            const double send = up ? v[k] : v[k | M];
+            const double recv = f8_xor_lane<M>(send);
+            v[k] = up ? recv : v[k];
+            v[k | M] = up ? v[k | M] : recv;
+        }
+    });
 }
 
 // multipliers of one round in the order [j = 2][j = 1: u = 0, 1][j = 0: u = 0..3] (j = register bit); `tw(s)` yields the
@@ -159,7 +229,7 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
     double* const row0 = tile_lds + f8_slot(f8_base<0>(t));
     double* const row1 = tile_lds + f8_slot(f8_base<1>(t));
     double* const row2 = tile_lds + f8_slot(f8_base<2>(t));
-    double* const row3 = tile_lds + f8_slot(f8_base<3>(t));
+    [[maybe_unused]] double* const row3 = tile_lds + f8_slot(f8_base<3>(t));
     const double* const tw2 = tw_lds;                                   // natural-order sub-tables of bits 5, 4, 3
     const double* const tw3 = tw_lds + kF8TwShared + t;                 // this lane's 7 multipliers, stride 512
     const uint32_t e5 = f8_base<2>(t) >> 6, e4 = f8_base<2>(t) >> 5, e3 = f8_base<2>(t) >> 4;
@@ -187,7 +257,14 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
         {
             const rsrc_t src = make_rsrc(rws + ((((size_t)j * K + i) << p.logn) + tile_pos), 4096u * 8u);
 #pragma unroll
-            for (int k = 0; k < kF8Regs; ++k) v[k] = __longlong_as_double((long long)buf_load64(src, t * 8u, (uint32_t)k * 4096u));
+            for (int k = 0; k < kF8Regs; ++k) {
+#if LSR_F8_ABLATE & 1
+                v[k] = (double)(t * 8u + k + i);
+                (void)src;
+#else
+                v[k] = __longlong_as_double((long long)buf_load64<LSR_F8_LOAD_AUX>(src, t * 8u, (uint32_t)k * 4096u));
+#endif
+            }
         }
         f8_forward_round(v, tw_r0, p);
         if (i > 0) __syncthreads();                      // the previous polynomial's last LDS reads are done
@@ -212,23 +289,58 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) v[k] = row2[f8_slot((uint32_t)k << 3)];
         f8_forward_round(v, tw_r2, p);
+#if LSR_F8_WAVE_XCHG
+        f8_transpose_regs_lanes(v, t);
+#else
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) row2[f8_slot((uint32_t)k << 3)] = v[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) v[k] = row3[k];
+#endif
         f8_forward_round(v, tw_r3, p);
         // acc[c] += A_hat[i][c] o r_hat_i on this lane's 8 positions
-        const double* const mat = a_perm + ((((size_t)tile * K + i) * K) << 12) + (size_t)t * 2;
+        [[maybe_unused]] const double* const mat = a_perm + ((((size_t)tile * K + i) * K) << 12) + (size_t)t * 2;
+#if LSR_F8_MAT_AHEAD
+        {   // rolling window of four 16-byte matrix loads: each slot is refilled for the next component as soon as its two
+            // products are issued, so a wave waits for L2 once per polynomial instead of once per load
+            double2 a[4];
+            // buffer addressing: SGPR base of this (tile, i) slab, one lane offset, the (c, kp) offset in the scalar operand
+            const rsrc_t slab = make_rsrc(a_perm + ((((size_t)tile * K + i) * K) << 12), (uint32_t)K * 4u * 512u * 16u);
+            const auto fetch = [&](int c, int kp) {
+                uint64_t lo, hi;
+                buf_load128(slab, t * 16u, (uint32_t)(c * 4 + kp) * 8192u, lo, hi);
+                return make_double2(__longlong_as_double((long long)lo), __longlong_as_double((long long)hi));
+            };
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) a[kp] = fetch(0, kp);
+            static_for<0, K>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) {
+                    const double2 cur = a[kp];
+                    if constexpr (c + 1 < K) a[kp] = fetch(c + 1, kp);
+                    acc[c][2 * kp] += mulmod_f64(v[2 * kp], cur.x, p.qd, p.inv_qd);
+                    acc[c][2 * kp + 1] += mulmod_f64(v[2 * kp + 1], cur.y, p.qd, p.inv_qd);
+                }
+            });
+        }
+#else
 #pragma unroll
         for (int c = 0; c < K; ++c) {
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) {
+#if LSR_F8_ABLATE & 2
+                const double2 a = make_double2((double)(c + 3), (double)(kp + 5 + i));
+                (void)mat;
+#else
                 const double2 a = *reinterpret_cast<const double2*>(mat + (((size_t)c * 4 + kp) << 10));
+#endif
                 acc[c][2 * kp] += mulmod_f64(v[2 * kp], a.x, p.qd, p.inv_qd);
                 acc[c][2 * kp + 1] += mulmod_f64(v[2 * kp + 1], a.y, p.qd, p.inv_qd);
             }
         }
+#endif
 #if LSR_F8_TOUCH
         asm volatile("" ::"v"(touch));
 #endif
@@ -246,6 +358,11 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) x[k] = recentre_f64(acc[c][k], p.qd, p.inv_qd);
         f8_inverse_round<false>(x, tw_r3, p);             // |x| <= 4 q
+#if LSR_F8_WAVE_XCHG
+        f8_transpose_regs_lanes(x, t);
+        f8_inverse_round<true>(x, tw_r2, p);              // 32 q -> q/2
+        if constexpr (c > 0) __syncthreads();            // the previous component's last LDS reads are done
+#else
         if constexpr (c > 0) __syncthreads();            // the previous component's last LDS reads are done
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) row3[k] = x[k];
@@ -253,6 +370,7 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) x[k] = row2[f8_slot((uint32_t)k << 3)];
         f8_inverse_round<true>(x, tw_r2, p);              // 32 q -> q/2
+#endif
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) row2[f8_slot((uint32_t)k << 3)] = x[k];
         __syncthreads();
@@ -267,7 +385,13 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
         f8_inverse_round<true>(x, tw_r0, p);              // 32 q -> q/2: what the strided round expects
         const rsrc_t dst = make_rsrc(u + ((((size_t)j * K + c) << p.logn) + tile_pos), 4096u * 8u);
 #pragma unroll
-        for (int k = 0; k < kF8Regs; ++k) buf_store64(dst, t * 8u, (uint32_t)k * 4096u, (uint64_t)__double_as_longlong(x[k]));
+        for (int k = 0; k < kF8Regs; ++k) {
+#if LSR_F8_ABLATE & 4
+            if (x[k] == 12345.678) buf_store64(dst, t * 8u, (uint32_t)k * 4096u, (uint64_t)__double_as_longlong(x[k]));
+#else
+            buf_store64<LSR_F8_STORE_AUX>(dst, t * 8u, (uint32_t)k * 4096u, (uint64_t)__double_as_longlong(x[k]));
+#endif
+        }
     });
 }
 
