@@ -336,6 +336,43 @@ def test_config3_matvec_workload(pkg, oracle):
     lctx.close()
 
 
+@pytest.mark.parametrize("n,k,batch", [(65536, 1, 3), (65536, 2, 5), (65536, 3, 2), (65536, 4, 67), (131072, 1, 2), (131072, 3, 3), (131072, 4, 2)])
+def test_fused_pipeline_every_rank_and_degree(pkg, oracle, n, k, batch):
+    """The fused NTT -> A^T product -> INTT pipeline serves n = 2^16 and 2^17 at ranks 1..4 (other shapes use the unfused
+    kernels): u = INTT(A^T NTT(r)) + e1 bit-exact against the oracle, with e1 given and with e1 sampled per chunk on the
+    device; a batch that is not a multiple of the chunk (64 vectors at k = 4) crosses a chunk and a stream boundary; r is left
+    untouched by the fused path."""
+    import torch
+    q = oracle.L.oracle_lwe_select_modulus(0, n)
+    lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xF00D + k)
+    assert lctx.commit_modulus == q
+    a_hat = lctx.public_matrix()
+    r = np.stack([oracle.splitmix(0xC0FFEE + j, q, k * n).reshape(k, n) for j in range(batch)])
+    seeds = (np.arange(batch, dtype=np.uint64) + np.uint64(7)) * np.uint64(0x9E3779B9)
+    picks = sorted({0, batch // 2, batch - 1, min(63, batch - 1), min(64, batch - 1)})
+    e1 = np.zeros((batch, k, n), dtype=np.uint64)
+    s = torch.cuda.current_stream().cuda_stream
+    d_e1 = torch.empty((batch, k, n), dtype=torch.int64, device="cuda")
+    assert lctx._lib.lsr_lwe_sample_blinding_device(lctx.handle, d_e1.data_ptr(), batch, seeds.ctypes.data, s) == 0
+    for j in picks:
+        ej = np.stack([oracle.sample_gaussian_seeded(n, 3.19, int(seeds[j]), 5, i) for i in range(k)])
+        e1[j] = np.where(ej < 0, ej + q, ej).astype(np.uint64)
+        assert np.array_equal(d_e1[j].cpu().numpy().view(np.uint64), e1[j])
+    d_r = torch.from_numpy(r.view(np.int64)).cuda()
+    d_u = torch.empty_like(d_r)
+    assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), d_e1.data_ptr(), d_u.data_ptr(), batch, None, s) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_r.cpu().numpy().view(np.uint64), r)                   # the fused path only reads r
+    given = d_u.clone()
+    for j in picks:
+        assert np.array_equal(given[j].cpu().numpy().view(np.uint64), oracle.mlwe_matvec(q, n, k, a_hat, r[j], e1[j])), (n, k, j)
+    d_u.zero_()
+    assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), None, d_u.data_ptr(), batch, seeds.ctypes.data, s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(d_u, given)                                                  # every vector, not only the picks
+    lctx.close()
+
+
 def test_config3_full_size_device_resident(pkg, oracle):
     """BASELINE config 3 at FULL size: rank 4, n = 2^16, 1024 witness vectors (2 GiB of r), device-resident, through
     lsr_mlwe_matvec_batch_device with e1 drawn by the seeded CDT sampler (sigma = 3.19).  r_j uniform from splitmix64
