@@ -269,10 +269,14 @@ struct LweContext {
     // fused matrix–vector pipeline (lsr_commit_fused.hpp): lane-major copy of A_hat, per-stream chunk workspaces, side streams
     static constexpr int kMaxSide = 4;
     lsr::DeviceBuffer<double> a_perm;
+    lsr::DeviceBuffer<double> a_perm8;     // layout of the 8 + 8 pipeline (n = 2^16 only)
     mutable lsr::DeviceBuffer<uint64_t> ws_mid, ws_e1_slots;
     mutable hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
     mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
     mutable int n_side = 0;
+    // two-lane pipeline of the 8 + 8 split: rings of events that order chunk c's outer passes and middle stage across the lanes
+    static constexpr int kRing = 4;
+    mutable hipEvent_t ev_outer[kRing] = {nullptr, nullptr, nullptr, nullptr}, ev_middle[kRing] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace lsr {
@@ -402,6 +406,11 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
             c->a_perm.allocate((size_t)k * kn);
             hipLaunchKernelGGL(f8_permute_matrix_kernel, dim3(grid_for((uint64_t)k * kn)), dim3(256), 0, s, c->a_perm.ptr, c->a_hat.ptr, k, c->logn);
             LSR_HIP(hipGetLastError());
+            if (c->logn == 16) {
+                c->a_perm8.allocate((size_t)k * kn);
+                hipLaunchKernelGGL(m8_permute_matrix_kernel, dim3(grid_for((uint64_t)k * kn)), dim3(256), 0, s, c->a_perm8.ptr, c->a_hat.ptr, k, c->logn);
+                LSR_HIP(hipGetLastError());
+            }
         }
         LSR_HIP(hipStreamSynchronize(s));
         LSR_HIP(hipMemset(sec_key.ptr, 0, 32));
@@ -429,7 +438,7 @@ static void destroy_lwe_context(LweContext* c) {
         c->a_hat.release(); c->s_hat.release(); c->b_hat.release(); c->cdf.release();
         c->ws_r.release(); c->ws_e1.release(); c->ws_e2.release(); c->ws_u.release(); c->ws_v.release();
         c->ws_dm.release(); c->ws_keys.release(); c->ws_flag.release();
-        c->a_perm.release(); c->ws_mid.release();
+        c->a_perm.release(); c->a_perm8.release(); c->ws_mid.release();
         if (c->ws_e1_slots.ptr) (void)hipMemset(c->ws_e1_slots.ptr, 0, c->ws_e1_slots.count * 8);
         c->ws_e1_slots.release();
         for (int i = 0; i < c->n_side; ++i) {
@@ -437,6 +446,10 @@ static void destroy_lwe_context(LweContext* c) {
             if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         }
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        for (int i = 0; i < LweContext::kRing; ++i) {
+            if (c->ev_outer[i]) (void)hipEventDestroy(c->ev_outer[i]);
+            if (c->ev_middle[i]) (void)hipEventDestroy(c->ev_middle[i]);
+        }
         if (c->host_stage) (void)hipHostFree(c->host_stage);
     } catch (...) {
     }
@@ -463,15 +476,117 @@ static void launch_mid(const LweContext& c, const uint64_t* ws, uint64_t* d_u, s
     LSR_HIP(hipGetLastError());
 }
 
+template <int K>
+static void launch_mid8(const LweContext& c, const uint64_t* ws, uint64_t* d_u, size_t vectors, hipStream_t s) {
+    // 8 waves per workgroup (default): the middle stage has the CU to itself; LAMBDA_SNARK_COMMIT_MID_WAVES=4: three workgroups
+    // per CU by LDS, one wave slot per SIMD left for the outer passes of a neighbouring chunk (for the two-lane schedule)
+    if (env_int("LAMBDA_SNARK_COMMIT_MID_WAVES", 8, 4, 8) == 8) {
+        hipLaunchKernelGGL((mlwe_mid8_w8<K>), dim3(static_cast<unsigned>(vectors << 4)), dim3(512), 0, s, ws, d_u, c.a_perm8.ptr, (uint32_t)vectors,
+                           c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr);
+    } else {
+        hipLaunchKernelGGL((mlwe_mid8_w4<K>), dim3(static_cast<unsigned>(vectors << 5)), dim3(256), 0, s, ws, d_u, c.a_perm8.ptr, (uint32_t)vectors,
+                           c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr);
+    }
+    LSR_HIP(hipGetLastError());
+}
+
 // Fused pipeline (caller holds c.mutex): per chunk of witness vectors
 //   top forward round r -> workspace | 12 forward stages x k, A_hat^T product, 12 inverse stages x k -> u | top inverse round (+ e1)
 // with the chunks dealt round-robin to side streams, so that the FP64-bound middle kernel of one chunk runs beside the
 // HBM-bound outer rounds of its neighbours.  d_r is only read.
+// The 8 + 8 split (n = 2^16) as a TWO-LANE software pipeline (experimental, off by default).  Lane "outer" (one stream) runs the
+// memory-bound passes of all chunks back to back — F(0), F(1), I(0), F(2), I(1), ... — lane "middle" (another stream) the
+// FP64-bound stages M(0), M(1), ... with M(c) after F(c) and I(c) after M(c) (events).  With LAMBDA_SNARK_COMMIT_MID_WAVES=4 the
+// middle kernel takes three workgroups per CU by construction and leaves a wave slot per SIMD, 34 KiB of LDS and >= 104 VGPRs,
+// so F(c+1) / I(c-1) run beside M(c) on every CU.  Round-robin streams do not give this (identical per-chunk programs fall
+// into lockstep — F beside F, M beside M); the two lanes do overlap (kernel trace in profiles/r02_commit_split_88.txt), but
+// each kernel then takes about twice as long — the outer passes, with their LDS exchange and barrier, are latency-bound at one
+// workgroup per CU — so the schedule loses (3.55 vs 3.3 ms).  tools/ubench_concurrency.hip shows the mechanism itself works.
+static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s,
+                                 const uint64_t* d_keys) {
+    const uint32_t k = c.k;
+    const size_t vec_words = (size_t)k << c.logn;
+    const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_CHUNK_MIB", 128, 1, 4096);
+    const size_t chunk = std::max<size_t>(1, (chunk_mib << 20) / (vec_words * 8));
+    const size_t chunks = (batch + chunk - 1) / chunk;
+    while (c.n_side < 2) {
+        LSR_HIP(hipStreamCreateWithFlags(&c.side[c.n_side], hipStreamNonBlocking));
+        LSR_HIP(hipEventCreateWithFlags(&c.ev_join[c.n_side], hipEventDisableTiming));
+        ++c.n_side;
+    }
+    if (!c.ev_fork) LSR_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < LweContext::kRing; ++i) {
+        if (!c.ev_outer[i]) LSR_HIP(hipEventCreateWithFlags(&c.ev_outer[i], hipEventDisableTiming));
+        if (!c.ev_middle[i]) LSR_HIP(hipEventCreateWithFlags(&c.ev_middle[i], hipEventDisableTiming));
+    }
+    constexpr size_t kSlots = 3;                                       // workspace slots: F(c + 3) is enqueued behind I(c), which waits for M(c)
+    const size_t slot_words = std::min(chunk, batch) * vec_words;
+    if (c.ws_mid.count < slot_words * kSlots) c.ws_mid.allocate(slot_words * kSlots);
+    const bool sample = !d_e1 && d_keys;
+    if (sample && c.ws_e1_slots.count < slot_words * kSlots) c.ws_e1_slots.allocate(slot_words * kSlots);
+    hipStream_t outer = c.side[0], middle = c.side[1];
+    LSR_HIP(hipEventRecord(c.ev_fork, s));
+    LSR_HIP(hipStreamWaitEvent(outer, c.ev_fork, 0));
+    LSR_HIP(hipStreamWaitEvent(middle, c.ev_fork, 0));
+    const RoundConsts<ArithF64> cs{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64};
+    auto span = [&](size_t ci, size_t* first, size_t* now) { *first = ci * chunk; *now = std::min(chunk, batch - *first); };
+    auto forward = [&](size_t ci) {
+        size_t first, now; span(ci, &first, &now);
+        uint64_t* const ws = c.ws_mid.ptr + (ci % kSlots) * slot_words;
+        hipLaunchKernelGGL(cols8_forward, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, ws, d_r + first * vec_words,
+                           (uint32_t)(now * k), c.ntt->mod, c.ntt->fwd_f64.ptr);
+        LSR_HIP(hipEventRecord(c.ev_outer[ci % LweContext::kRing], outer));
+    };
+    auto middle_stage = [&](size_t ci) {
+        size_t first, now; span(ci, &first, &now);
+        uint64_t* const ws = c.ws_mid.ptr + (ci % kSlots) * slot_words;
+        if (sample)      // the chunk's blinding residues: FP64-free integer work, on the ALU-bound lane
+            launch_gaussian(GaussianJob{c.ws_e1_slots.ptr + (ci % kSlots) * slot_words, d_keys + 4 * first, 0, k, kDomE1, c.n, now * k, c.q}, c.cdf.ptr,
+                            c.cdf_entries, middle);
+        LSR_HIP(hipStreamWaitEvent(middle, c.ev_outer[ci % LweContext::kRing], 0));
+        uint64_t* const out = d_u + first * vec_words;
+        switch (k) {
+            case 1: launch_mid8<1>(c, ws, out, now, middle); break;
+            case 2: launch_mid8<2>(c, ws, out, now, middle); break;
+            case 3: launch_mid8<3>(c, ws, out, now, middle); break;
+            default: launch_mid8<4>(c, ws, out, now, middle); break;
+        }
+        LSR_HIP(hipEventRecord(c.ev_middle[ci % LweContext::kRing], middle));
+    };
+    auto inverse = [&](size_t ci) {
+        size_t first, now; span(ci, &first, &now);
+        const uint64_t* blind = d_e1 ? d_e1 + first * vec_words : (sample ? c.ws_e1_slots.ptr + (ci % kSlots) * slot_words : nullptr);
+        LSR_HIP(hipStreamWaitEvent(outer, c.ev_middle[ci % LweContext::kRing], 0));
+        hipLaunchKernelGGL(cols8_inverse, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, d_u + first * vec_words, (uint32_t)(now * k),
+                           c.ntt->mod, c.ntt->inv_f64.ptr, cs, blind);
+    };
+    // enqueue order respects the event rings (an event is re-recorded only after every wait on its previous record is enqueued)
+    forward(0);
+    for (size_t ci = 0; ci < chunks; ++ci) {
+        if (ci + 1 < chunks) forward(ci + 1);
+        middle_stage(ci);
+        inverse(ci);
+    }
+    LSR_HIP(hipGetLastError());
+    for (int i = 0; i < 2; ++i) {
+        LSR_HIP(hipEventRecord(c.ev_join[i], c.side[i]));
+        LSR_HIP(hipStreamWaitEvent(s, c.ev_join[i], 0));
+    }
+}
+
 // d_e1 == NULL && d_keys != NULL: the blinding residues of a chunk are sampled (domain 5, per-vector keys d_keys[batch][4]) into
 // a chunk-sized buffer on the chunk's stream right before its transforms — no [batch][k][n] array of e1 ever exists, and the
 // sampling of one chunk runs beside the transforms of its neighbours.
 static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s,
                               const uint64_t* d_keys = nullptr) {
+    // Alternative pipelines for n = 2^16, kept selectable (bit-exact, tests/test_commitment_gpu.py; measurements in
+    // profiles/r02_commit_split_88.txt): LAMBDA_SNARK_COMMIT_SPLIT=88 — the 8 + 8 split with the barrier-free middle stage —
+    // ties with the default 4 + 12 split (3.22-3.31 ms per 1024 rank-4 vectors either way); LAMBDA_SNARK_COMMIT_TWO_LANE=1 adds
+    // the two-lane schedule, which is slower today because the outer passes crawl at one workgroup per CU.
+    if (c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) == 88 && env_int("LAMBDA_SNARK_COMMIT_TWO_LANE", 0, 0, 1)) {
+        mlwe_matvec_two_lane(c, d_r, d_e1, d_u, batch, s, d_keys);
+        return;
+    }
     const uint32_t k = c.k;
     const size_t vec_words = (size_t)k << c.logn;
     const int want = env_int("LAMBDA_SNARK_COMMIT_STREAMS", 2, 1, LweContext::kMaxSide);
@@ -487,6 +602,7 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
     const size_t slot_words = std::min(chunk, batch) * vec_words;
     if (c.ws_mid.count < slot_words * streams) c.ws_mid.allocate(slot_words * streams);
     const bool sample = !d_e1 && d_keys;
+    const bool split88 = c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) == 88;
     if (sample && c.ws_e1_slots.count < slot_words * streams) c.ws_e1_slots.allocate(slot_words * streams);
     LSR_HIP(hipEventRecord(c.ev_fork, s));
     for (int i = 0; i < streams; ++i) LSR_HIP(hipStreamWaitEvent(c.side[i], c.ev_fork, 0));
@@ -501,14 +617,30 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
             launch_gaussian(GaussianJob{slot, d_keys + 4 * first, 0, k, kDomE1, c.n, now * k, c.q}, c.cdf.ptr, c.cdf_entries, st);
             blind = slot;
         }
+        uint64_t* const out = d_u + first * vec_words;
+        if (split88) {   // n = 2^16: bits 15..8 | bits 7..0, product, bits 0..7 | bits 8..15 (lsr_commit_fused.hpp, second half)
+            const unsigned cols_grid = static_cast<unsigned>(now * k * 16);
+            hipLaunchKernelGGL(cols8_forward, dim3(cols_grid), dim3(kC8Threads), 0, st, ws, d_r + first * vec_words, (uint32_t)(now * k), c.ntt->mod,
+                               c.ntt->fwd_f64.ptr);
+            switch (k) {
+                case 1: launch_mid8<1>(c, ws, out, now, st); break;
+                case 2: launch_mid8<2>(c, ws, out, now, st); break;
+                case 3: launch_mid8<3>(c, ws, out, now, st); break;
+                default: launch_mid8<4>(c, ws, out, now, st); break;
+            }
+            hipLaunchKernelGGL(cols8_inverse, dim3(cols_grid), dim3(kC8Threads), 0, st, out, (uint32_t)(now * k), c.ntt->mod, c.ntt->inv_f64.ptr,
+                               RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64}, blind);
+            LSR_HIP(hipGetLastError());
+            continue;
+        }
         launch_top_round_forward(*c.ntt, ws, d_r + first * vec_words, now * k, st);
         switch (k) {
-            case 1: launch_mid<1>(c, ws, d_u + first * vec_words, now, st); break;
-            case 2: launch_mid<2>(c, ws, d_u + first * vec_words, now, st); break;
-            case 3: launch_mid<3>(c, ws, d_u + first * vec_words, now, st); break;
-            default: launch_mid<4>(c, ws, d_u + first * vec_words, now, st); break;
+            case 1: launch_mid<1>(c, ws, out, now, st); break;
+            case 2: launch_mid<2>(c, ws, out, now, st); break;
+            case 3: launch_mid<3>(c, ws, out, now, st); break;
+            default: launch_mid<4>(c, ws, out, now, st); break;
         }
-        launch_top_round_inverse(*c.ntt, d_u + first * vec_words, now * k, st, blind);
+        launch_top_round_inverse(*c.ntt, out, now * k, st, blind);
     }
     for (int i = 0; i < streams; ++i) {
         LSR_HIP(hipEventRecord(c.ev_join[i], c.side[i]));

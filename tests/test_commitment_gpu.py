@@ -373,6 +373,33 @@ def test_fused_pipeline_every_rank_and_degree(pkg, oracle, n, k, batch):
     lctx.close()
 
 
+@pytest.mark.parametrize("env", [{"LAMBDA_SNARK_COMMIT_SPLIT": "88"}, {"LAMBDA_SNARK_COMMIT_SPLIT": "88", "LAMBDA_SNARK_COMMIT_MID_WAVES": "4"},
+                                 {"LAMBDA_SNARK_COMMIT_SPLIT": "88", "LAMBDA_SNARK_COMMIT_MID_WAVES": "4", "LAMBDA_SNARK_COMMIT_TWO_LANE": "1"},
+                                 {"LAMBDA_SNARK_COMMIT_FUSED": "0"}])
+def test_alternative_commit_pipelines_agree(pkg, oracle, env, monkeypatch):
+    """The selectable pipelines of the n = 2^16 matrix–vector product — the 8 + 8 split with the barrier-free middle stage
+    (8- and 4-wave workgroups), its two-lane schedule, and the unfused round-1 kernels — give the oracle's words."""
+    import torch
+    for key, value in env.items():
+        monkeypatch.setenv(key, value)
+    q, n, batch = 17592182243329, 65536, 70
+    s = torch.cuda.current_stream().cuda_stream
+    for k in (4, 2):
+        lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xBEEF + k)
+        a_hat = lctx.public_matrix()
+        r = np.stack([oracle.splitmix(0xC0FFEE + j, q, k * n).reshape(k, n) for j in range(batch)])
+        seeds = (np.arange(batch, dtype=np.uint64) + np.uint64(3)) * np.uint64(0x9E3779B9)
+        d_r = torch.from_numpy(r.view(np.int64)).cuda()
+        d_u = torch.empty_like(d_r)
+        assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), None, d_u.data_ptr(), batch, seeds.ctypes.data, s) == 0
+        torch.cuda.synchronize()
+        for j in (0, 63, 64, batch - 1):
+            e1 = np.stack([oracle.sample_gaussian_seeded(n, 3.19, int(seeds[j]), 5, i) for i in range(k)])
+            e1 = np.where(e1 < 0, e1 + q, e1).astype(np.uint64)
+            assert np.array_equal(d_u[j].cpu().numpy().view(np.uint64), oracle.mlwe_matvec(q, n, k, a_hat, r[j], e1)), (env, k, j)
+        lctx.close()
+
+
 def test_config3_full_size_device_resident(pkg, oracle):
     """BASELINE config 3 at FULL size: rank 4, n = 2^16, 1024 witness vectors (2 GiB of r), device-resident, through
     lsr_mlwe_matvec_batch_device with e1 drawn by the seeded CDT sampler (sigma = 3.19).  r_j uniform from splitmix64

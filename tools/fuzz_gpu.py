@@ -117,8 +117,9 @@ while time.time() < deadline:
         seed_key = int(rng.integers(1, 2**62))
         ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=seed_key)
         cnt = int(rng.integers(1, 6)); ml = int(rng.integers(1, min(n, 64) + 1))
-        msgs = rng.integers(0, 2**20, size=(cnt, ml), dtype=np.uint64)
+        msgs = rng.integers(0, ctx.plain_modulus, size=(cnt, ml), dtype=np.uint64)   # words >= t never open (commitment.cpp:223-226)
         seeds = rng.integers(1, 2**62, size=cnt, dtype=np.uint64)
+        if cnt > 1 and rng.integers(0, 2): seeds[1] = seeds[0]                     # a reused seed: the blinding is message-bound
         coms = pkg.Commitment.batch(ctx, msgs, seeds)
         for i in range(cnt):
             if not np.array_equal(coms[i].as_words(), orc.lwe_commit(q, n, k, 3.19, seed_key, msgs[i], int(seeds[i]))): report("batch commit", n=n, k=k, i=i)
@@ -143,12 +144,15 @@ while time.time() < deadline:
         if q == 0: continue
         seed_key = int(rng.integers(1, 2**62))
         ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=seed_key)
-        msg = rng.integers(0, 2**20, size=int(rng.integers(0, n + 3)), dtype=np.uint64)
+        msg = rng.integers(0, 2**21, size=int(rng.integers(0, n + 3)), dtype=np.uint64)   # some words above t on purpose
         seed = int(rng.integers(1, 2**62))
         com = pkg.Commitment(ctx, msg, seed)
         want = orc.lwe_commit(q, n, k, 3.19, seed_key, msg % np.uint64(q), seed)     # Commitment::new reduces mod the REQUESTED modulus (commitment.rs:33-36)
         if not np.array_equal(com.as_words(), want): report("commit", q=q, n=n, k=k, len=len(msg))
-        if not pkg.verify_opening_with_context(ctx, com, (msg % np.uint64(q))[:n]): report("verify", q=q, n=n, k=k)
+        shown = (msg % np.uint64(q))[:n]
+        t = np.uint64(ctx.plain_modulus)
+        if pkg.verify_opening_with_context(ctx, com, shown) != bool((shown < t).all()): report("verify raw words", q=q, n=n, k=k)
+        if not pkg.verify_opening_with_context(ctx, com, shown % t): report("verify", q=q, n=n, k=k)
         com.free(); ctx.close()
     if cases % 50 == 0:
         print(f"{cases} cases, {bad} mismatches, {deadline - time.time():.0f} s left", flush=True)

@@ -51,6 +51,21 @@ __global__ void __launch_bounds__(256) pass2(uint64_t* __restrict__ d, size_t to
     for (int k = 0; k < 16 / W; ++k) st<W, NTS>(d + base + (size_t)k * 256 * W, v[k]);
 }
 
+// pass 1 of an 8 + 8 split: a 256-lane workgroup owns 16 adjacent columns x 256 rows of a 256 x 256 polynomial (rows 2 KiB
+// apart, 128-byte row segments); lane t holds rows (t >> 4) + 16 k of column t & 15
+template <bool NTL, bool NTS>
+__global__ void __launch_bounds__(256) pass1_cols(uint64_t* __restrict__ d, size_t total) {
+    const size_t tile = blockIdx.x;                      // 16 column blocks per polynomial
+    const size_t base = ((tile >> 4) << 16) + ((tile & 15) << 4) + (threadIdx.x & 15) + ((size_t)(threadIdx.x >> 4) << 8);
+    uint64_t v[16][1];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ld<1, NTL>(d + base + ((size_t)k << 12), v[k]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k][0] = v[k][0] * 3 + v[(k + 1) & 15][0];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st<1, NTS>(d + base + ((size_t)k << 12), v[k]);
+}
+
 template <class F> static float timed(F&& launch, hipEvent_t a, hipEvent_t b) {
     std::vector<float> ms;
     for (int rep = 0; rep < 7; ++rep) {
@@ -93,5 +108,18 @@ int main() {
     printf("both   8B plain /  8B nt-load          %.3f\n", RUNB(1, false, false, 1, true, false));
     printf("both   8B nt-load / 8B plain           %.3f\n", RUNB(1, true, false, 1, false, false));
     printf("both   8B plain / 8B plain (again)     %.3f\n", RUNB(1, false, false, 1, false, false));
+#define RUNC(L1, S1) timed([&] { for (size_t c = 0; c < polys; c += chunk_polys) hipLaunchKernelGGL((pass1_cols<L1, S1>), dim3((unsigned)(chunk / 4096)), dim3(256), 0, 0, data + c * n, chunk); }, a, b)
+#define RUNCB(L1, S1, W2, L2, S2) timed([&] { for (size_t c = 0; c < polys; c += chunk_polys) { \
+        hipLaunchKernelGGL((pass1_cols<L1, S1>), dim3((unsigned)(chunk / 4096)), dim3(256), 0, 0, data + c * n, chunk); \
+        hipLaunchKernelGGL((pass2<W2, L2, S2>), dim3((unsigned)(chunk / 4096)), dim3(256), 0, 0, data + c * n, chunk); } }, a, b)
+    printf("pass1 16 cols x 256 rows (8 + 8 split), 8B plain   %.3f\n", RUNC(false, false));
+    printf("both  cols-tile plain / 8B nt-load+store            %.3f\n", RUNCB(false, false, 1, true, true));
+    printf("both  cols-tile plain / 8B plain                    %.3f\n", RUNCB(false, false, 1, false, false));
+    // occupancy sensitivity of the memory-bound passes: dynamic LDS padding limits the resident 256-lane workgroups per CU
+    for (unsigned pad : {0u, 36000u, 50000u, 70000u, 100000u}) {
+        const float t1 = timed([&] { for (size_t c = 0; c < polys; c += chunk_polys) hipLaunchKernelGGL((pass1<1, false, false>), dim3((unsigned)(chunk / 16 / 256)), dim3(256), pad, 0, data + c * n, chunk); }, a, b);
+        const float t2 = timed([&] { for (size_t c = 0; c < polys; c += chunk_polys) hipLaunchKernelGGL((pass1_cols<false, false>), dim3((unsigned)(chunk / 4096)), dim3(256), pad, 0, data + c * n, chunk); }, a, b);
+        printf("LDS pad %6u B (<= %u workgroups per CU): strided rows %.3f ms, 16-column tiles %.3f ms\n", pad, pad ? 163840u / pad : 8u, t1, t2);
+    }
     return 0;
 }
