@@ -160,6 +160,8 @@ def _share_hip_runtime_with_torch():
     liblambda_snark_core.so (NEEDED libamdhip64.so.7) binds to that same runtime.  Without PyTorch the system
     runtime under /opt/rocm is used, as a Rust or C++ caller would."""
     import importlib.util
+    if os.environ.get("LAMBDA_SNARK_SYSTEM_HIP"):      # a process that never imports PyTorch: bind to the system runtime like a C caller
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
