@@ -533,7 +533,7 @@ static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const
     auto forward = [&](size_t ci) {
         size_t first, now; span(ci, &first, &now);
         uint64_t* const ws = c.ws_mid.ptr + (ci % kSlots) * slot_words;
-        hipLaunchKernelGGL(cols8_forward, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, ws, d_r + first * vec_words,
+        hipLaunchKernelGGL(cols8_forward<true>, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, ws, d_r + first * vec_words,
                            (uint32_t)(now * k), c.ntt->mod, c.ntt->fwd_f64.ptr);
         LSR_HIP(hipEventRecord(c.ev_outer[ci % LweContext::kRing], outer));
     };
@@ -557,7 +557,7 @@ static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const
         size_t first, now; span(ci, &first, &now);
         const uint64_t* blind = d_e1 ? d_e1 + first * vec_words : (sample ? c.ws_e1_slots.ptr + (ci % kSlots) * slot_words : nullptr);
         LSR_HIP(hipStreamWaitEvent(outer, c.ev_middle[ci % LweContext::kRing], 0));
-        hipLaunchKernelGGL(cols8_inverse, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, d_u + first * vec_words, (uint32_t)(now * k),
+        hipLaunchKernelGGL(cols8_inverse<true>, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, d_u + first * vec_words, (uint32_t)(now * k),
                            c.ntt->mod, c.ntt->inv_f64.ptr, cs, blind);
     };
     // enqueue order respects the event rings (an event is re-recorded only after every wait on its previous record is enqueued)
@@ -620,7 +620,7 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
         uint64_t* const out = d_u + first * vec_words;
         if (split88) {   // n = 2^16: bits 15..8 | bits 7..0, product, bits 0..7 | bits 8..15 (lsr_commit_fused.hpp, second half)
             const unsigned cols_grid = static_cast<unsigned>(now * k * 16);
-            hipLaunchKernelGGL(cols8_forward, dim3(cols_grid), dim3(kC8Threads), 0, st, ws, d_r + first * vec_words, (uint32_t)(now * k), c.ntt->mod,
+            hipLaunchKernelGGL(cols8_forward<false>, dim3(cols_grid), dim3(kC8Threads), 0, st, ws, d_r + first * vec_words, (uint32_t)(now * k), c.ntt->mod,
                                c.ntt->fwd_f64.ptr);
             switch (k) {
                 case 1: launch_mid8<1>(c, ws, out, now, st); break;
@@ -628,7 +628,7 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
                 case 3: launch_mid8<3>(c, ws, out, now, st); break;
                 default: launch_mid8<4>(c, ws, out, now, st); break;
             }
-            hipLaunchKernelGGL(cols8_inverse, dim3(cols_grid), dim3(kC8Threads), 0, st, out, (uint32_t)(now * k), c.ntt->mod, c.ntt->inv_f64.ptr,
+            hipLaunchKernelGGL(cols8_inverse<false>, dim3(cols_grid), dim3(kC8Threads), 0, st, out, (uint32_t)(now * k), c.ntt->mod, c.ntt->inv_f64.ptr,
                                RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64}, blind);
             LSR_HIP(hipGetLastError());
             continue;

@@ -31,19 +31,15 @@
 #ifndef LSR_F8_TOUCH
 #define LSR_F8_TOUCH 1
 #endif
-// Exchange between the rounds of index bits [3,6) and [0,3): 0 = through the LDS tile (+ barrier), 1 = inside the wavefront
-// with __shfl_xor (the compiler picks DPP / ds_bpermute), 2 = inside the wavefront with explicit DPP moves
-// (quad_perm for lane^1, lane^2; row_shl/row_shr:4 under bank masks for lane^4).  The register field swaps places with
-// lane bits 0..2 — an 8 x 8 transpose among 8 neighbouring lanes — so no other lane of the workgroup is involved and the
-// exchange needs neither LDS storage nor a barrier (north_star: "ds_swizzle/ds_permute for the intra-wavefront transpose
-// stages"; measured in profiles/r02_fused_wave_exchange.txt).  3 = through LDS again but without the barrier: the group of 8
-// lanes owns a 64-slot block of the tile, so the round trip is private to the wavefront (no VALU spent on the transpose).
+// Exchange between the rounds of index bits [3,6) and [0,3): 2 (default) = inside the wavefront with explicit DPP moves
+// (quad_perm for lane^1, lane^2; row_shl/row_shr:4 under bank masks for lane^4), 0 = through the LDS tile (+ barrier).  The
+// register field swaps places with lane bits 0..2 — an 8 x 8 transpose among 8 neighbouring lanes — so no other lane of the
+// workgroup is involved and the exchange needs neither LDS storage nor a barrier (north_star: "ds_swizzle/ds_permute for the
+// intra-wavefront transpose stages").  Measured (profiles/r02_fused_wave_exchange.txt, r02_fused_mid_ablation.txt): DPP -21.5 %
+// LDS instructions, +14.7 % VALU, pipeline -1.5 %; the __shfl_xor form (-> ds_bpermute) and a barrier-free round trip through
+// a wave-private, XOR-swizzled LDS block were both slower and are not kept.
 #ifndef LSR_F8_WAVE_XCHG
 #define LSR_F8_WAVE_XCHG 2
-#endif
-// ablation builds for profiling only (results are wrong): bit 0 = no operand loads, bit 1 = no matrix loads, bit 2 = no stores
-#ifndef LSR_F8_ABLATE
-#define LSR_F8_ABLATE 0
 #endif
 // cache policy of the streamed tile operands and results (0 = default, 2 = nt): they pass through the XCD's L2 once, the matrix
 // slice is re-read by every workgroup
@@ -88,7 +84,6 @@ __host__ __device__ constexpr uint32_t f8_base(uint32_t t) {
 // value of lane (self ^ M), M in {1, 2, 4}
 template <int M>
 __device__ __forceinline__ double f8_xor_lane(double x) {
-#if LSR_F8_WAVE_XCHG == 2
     const long long bits = __double_as_longlong(x);
     int lo = (int)bits, hi = (int)(bits >> 32);
     if constexpr (M == 1) {
@@ -105,9 +100,6 @@ __device__ __forceinline__ double f8_xor_lane(double x) {
         hi = __builtin_amdgcn_update_dpp(hi, h0, 0x114, 0xF, 0xA, false);
     }
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-#else
-    return __shfl_xor(x, M, 64);
-#endif
 }
 // registers <-> lane bits 0..2: element (lane bit s = a, register bit s = b) moves to (lane bit s = b, register bit s = a)
 __device__ __forceinline__ void f8_transpose_regs_lanes(double (&v)[kF8Regs], uint32_t t) {
@@ -231,8 +223,6 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
     double* const row1 = tile_lds + f8_slot(f8_base<1>(t));
     double* const row2 = tile_lds + f8_slot(f8_base<2>(t));
     [[maybe_unused]] double* const row3 = tile_lds + f8_slot(f8_base<3>(t));
-    [[maybe_unused]] double* const grp8 = tile_lds + f8_slot((t >> 3) << 6);   // the 64-slot block of this lane's group of 8
-    [[maybe_unused]] const uint32_t j8 = t & 7u;
     const double* const tw2 = tw_lds;                                   // natural-order sub-tables of bits 5, 4, 3
     const double* const tw3 = tw_lds + kF8TwShared + t;                 // this lane's 7 multipliers, stride 512
     const uint32_t e5 = f8_base<2>(t) >> 6, e4 = f8_base<2>(t) >> 5, e3 = f8_base<2>(t) >> 4;
@@ -260,14 +250,7 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
         {
             const rsrc_t src = make_rsrc(rws + ((((size_t)j * K + i) << p.logn) + tile_pos), 4096u * 8u);
 #pragma unroll
-            for (int k = 0; k < kF8Regs; ++k) {
-#if LSR_F8_ABLATE & 1
-                v[k] = (double)(t * 8u + k + i);
-                (void)src;
-#else
-                v[k] = __longlong_as_double((long long)buf_load64<LSR_F8_LOAD_AUX>(src, t * 8u, (uint32_t)k * 4096u));
-#endif
-            }
+            for (int k = 0; k < kF8Regs; ++k) v[k] = __longlong_as_double((long long)buf_load64<LSR_F8_LOAD_AUX>(src, t * 8u, (uint32_t)k * 4096u));
         }
         f8_forward_round(v, tw_r0, p);
         if (i > 0) __syncthreads();                      // the previous polynomial's last LDS reads are done
@@ -301,19 +284,7 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
             return make_double2(__longlong_as_double((long long)lo), __longlong_as_double((long long)hi));
         };
 #endif
-#if LSR_F8_WAVE_XCHG == 3
-        // The 8 x 8 transpose stays inside a group of 8 neighbouring lanes, and that group owns a contiguous 64-slot block of
-        // the tile: element (a = index bits 0..2, b = index bits 3..5) is parked at (a ^ b) + 8 b of the block — conflict free
-        // for the writers (a = lane, b = register) and for the readers (a = register, b = lane) alike — and read back by the
-        // same wavefront, so the round trip needs no workgroup barrier (the DS operations of a wave complete in order).
-#pragma unroll
-        for (int k = 0; k < kF8Regs; ++k) grp8[(j8 ^ (uint32_t)k) + 8u * (uint32_t)k] = v[k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int k = 0; k < kF8Regs; ++k) v[k] = grp8[((uint32_t)k ^ j8) + 8u * j8];
-#elif LSR_F8_WAVE_XCHG
+#if LSR_F8_WAVE_XCHG
         f8_transpose_regs_lanes(v, t);
 #else
 #pragma unroll
@@ -346,12 +317,7 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
         for (int c = 0; c < K; ++c) {
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) {
-#if LSR_F8_ABLATE & 2
-                const double2 a = make_double2((double)(c + 3), (double)(kp + 5 + i));
-                (void)mat;
-#else
                 const double2 a = *reinterpret_cast<const double2*>(mat + (((size_t)c * 4 + kp) << 10));
-#endif
                 acc[c][2 * kp] += mulmod_f64(v[2 * kp], a.x, p.qd, p.inv_qd);
                 acc[c][2 * kp + 1] += mulmod_f64(v[2 * kp + 1], a.y, p.qd, p.inv_qd);
             }
@@ -374,17 +340,7 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) x[k] = recentre_f64(acc[c][k], p.qd, p.inv_qd);
         f8_inverse_round<false>(x, tw_r3, p);             // |x| <= 4 q
-#if LSR_F8_WAVE_XCHG == 3
-        if constexpr (c > 0) __syncthreads();            // the previous component's last LDS reads are done
-#pragma unroll
-        for (int k = 0; k < kF8Regs; ++k) grp8[((uint32_t)k ^ j8) + 8u * j8] = x[k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int k = 0; k < kF8Regs; ++k) x[k] = grp8[(j8 ^ (uint32_t)k) + 8u * (uint32_t)k];
-        f8_inverse_round<true>(x, tw_r2, p);              // 32 q -> q/2
-#elif LSR_F8_WAVE_XCHG
+#if LSR_F8_WAVE_XCHG
         f8_transpose_regs_lanes(x, t);
         f8_inverse_round<true>(x, tw_r2, p);              // 32 q -> q/2
         if constexpr (c > 0) __syncthreads();            // the previous component's last LDS reads are done
@@ -411,13 +367,7 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
         f8_inverse_round<true>(x, tw_r0, p);              // 32 q -> q/2: what the strided round expects
         const rsrc_t dst = make_rsrc(u + ((((size_t)j * K + c) << p.logn) + tile_pos), 4096u * 8u);
 #pragma unroll
-        for (int k = 0; k < kF8Regs; ++k) {
-#if LSR_F8_ABLATE & 4
-            if (x[k] == 12345.678) buf_store64(dst, t * 8u, (uint32_t)k * 4096u, (uint64_t)__double_as_longlong(x[k]));
-#else
-            buf_store64<LSR_F8_STORE_AUX>(dst, t * 8u, (uint32_t)k * 4096u, (uint64_t)__double_as_longlong(x[k]));
-#endif
-        }
+        for (int k = 0; k < kF8Regs; ++k) buf_store64<LSR_F8_STORE_AUX>(dst, t * 8u, (uint32_t)k * 4096u, (uint64_t)__double_as_longlong(x[k]));
     });
 }
 
@@ -443,6 +393,8 @@ constexpr uint32_t kC8LdsWords = 4096 + 16 * 16;      // tile index i at i + 16 
 
 // forward: stages of polynomial index bits 15..8 on a tile of 16 adjacent columns (bits 0..3; the column block = bits 4..7 comes
 // from the block index) x 256 rows (bits 8..15)
+// STREAM: every global access with the nt policy, so that the pass leaves the XCD's L2 to a co-resident middle stage (two-lane schedule)
+template <bool STREAM>
 __global__ void __launch_bounds__(kC8Threads) cols8_forward(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t polys, ModParams p,
                                                              const double* __restrict__ tw) {
     __shared__ double lds[kC8LdsWords];
@@ -455,7 +407,10 @@ __global__ void __launch_bounds__(kC8Threads) cols8_forward(uint64_t* __restrict
     double v[16];
     // round 1: registers = bits 12..15, this lane's row bits 8..11 = rr
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = A::load(src[base + ((uint32_t)k << 12) + (rr << 8)], p);
+    for (int k = 0; k < 16; ++k) {
+        const uint64_t* const at = src + base + ((uint32_t)k << 12) + (rr << 8);
+        v[k] = A::load(STREAM ? __builtin_nontemporal_load(at) : *at, p);
+    }
 #pragma unroll
     for (int j = 3; j >= 0; --j) {
         const int half = 1 << j;
@@ -483,10 +438,15 @@ __global__ void __launch_bounds__(kC8Threads) cols8_forward(uint64_t* __restrict
         }
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) dst[base + (rr << 12) + ((uint32_t)k << 8)] = (uint64_t)__double_as_longlong(v[k]);
+    for (int k = 0; k < 16; ++k) {
+        uint64_t* const at = dst + base + (rr << 12) + ((uint32_t)k << 8);
+        if (STREAM) __builtin_nontemporal_store((uint64_t)__double_as_longlong(v[k]), at);
+        else *at = (uint64_t)__double_as_longlong(v[k]);
+    }
 }
 
 // inverse: stages of bits 8..15 (Gentleman–Sande), n^-1 folded into the last one, + add (canonical residues, optional), canonical out
+template <bool STREAM>
 __global__ void __launch_bounds__(kC8Threads) cols8_inverse(uint64_t* __restrict__ data, uint32_t polys, ModParams p, const double* __restrict__ tw,
                                                              RoundConsts<ArithF64> cs, const uint64_t* __restrict__ add) {
     __shared__ double lds[kC8LdsWords];
@@ -519,7 +479,10 @@ __global__ void __launch_bounds__(kC8Threads) cols8_inverse(uint64_t* __restrict
     uint64_t blind[16];
     if (add != nullptr) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) blind[k] = add[base + ((uint32_t)k << 12) + (rr << 8)];
+        for (int k = 0; k < 16; ++k) {
+            const uint64_t* const at = add + base + ((uint32_t)k << 12) + (rr << 8);
+            blind[k] = STREAM ? __builtin_nontemporal_load(at) : *at;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {

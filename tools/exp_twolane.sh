@@ -2,13 +2,13 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r02_twolane
 rm -rf $out && mkdir -p $out
-t=$(timeout -k 10 300 python -m pytest tests/test_commitment_gpu.py -m gpu -x -q -k "config3 or fused_pipeline" 2>&1 | tail -1)
+t=$(LAMBDA_SNARK_COMMIT_SPLIT=88 LAMBDA_SNARK_COMMIT_TWO_LANE=1 LAMBDA_SNARK_COMMIT_MID_WAVES=4 timeout -k 10 300 python -m pytest tests/test_commitment_gpu.py -m gpu -x -q -k "config3 or fused_pipeline" 2>&1 | tail -1)
 echo "two-lane tests: $t"
 for rep in 1 2; do
 for cfg in "1 4 128" "1 4 64" "1 8 128" "0 8 128"; do set -- $cfg
-  echo -n "two_lane=$1 mid_waves=$2 chunk=$3: "; LAMBDA_SNARK_COMMIT_TWO_LANE=$1 LAMBDA_SNARK_COMMIT_MID_WAVES=$2 LAMBDA_SNARK_COMMIT_CHUNK_MIB=$3 timeout -k 10 120 python3 tools/commit_bench.py 2>&1 | grep -E "e1 given|on device" | tr '\n' ' '; echo
+  echo -n "two_lane=$1 mid_waves=$2 chunk=$3: "; LAMBDA_SNARK_COMMIT_SPLIT=88 LAMBDA_SNARK_COMMIT_TWO_LANE=$1 LAMBDA_SNARK_COMMIT_MID_WAVES=$2 LAMBDA_SNARK_COMMIT_CHUNK_MIB=$3 timeout -k 10 120 python3 tools/commit_bench.py 2>&1 | grep -E "e1 given|on device" | tr '\n' ' '; echo
 done; done
-J=512 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/t -- python3 tools/commit_bench.py > $out/t.log 2>&1
+J=512 LAMBDA_SNARK_COMMIT_SPLIT=88 LAMBDA_SNARK_COMMIT_TWO_LANE=1 LAMBDA_SNARK_COMMIT_MID_WAVES=4 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/t -- python3 tools/commit_bench.py > $out/t.log 2>&1
 python3 - $out/t <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
