@@ -277,6 +277,9 @@ struct LweContext {
     // two-lane pipeline of the 8 + 8 split: rings of events that order chunk c's outer passes and middle stage across the lanes
     static constexpr int kRing = 4;
     mutable hipEvent_t ev_outer[kRing] = {nullptr, nullptr, nullptr, nullptr}, ev_middle[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    // the two lanes' own streams: [0] outer passes, [1] middle stages; with lane_outer_cus > 0 they carry complementary CU masks
+    mutable hipStream_t lane[2] = {nullptr, nullptr};
+    mutable int lane_outer_cus = -1;
 };
 
 namespace lsr {
@@ -446,6 +449,8 @@ static void destroy_lwe_context(LweContext* c) {
             if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         }
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        for (int i = 0; i < 2; ++i)
+            if (c->lane[i]) (void)hipStreamDestroy(c->lane[i]);
         for (int i = 0; i < LweContext::kRing; ++i) {
             if (c->ev_outer[i]) (void)hipEventDestroy(c->ev_outer[i]);
             if (c->ev_middle[i]) (void)hipEventDestroy(c->ev_middle[i]);
@@ -490,30 +495,46 @@ static void launch_mid8(const LweContext& c, const uint64_t* ws, uint64_t* d_u, 
     LSR_HIP(hipGetLastError());
 }
 
-// Fused pipeline (caller holds c.mutex): per chunk of witness vectors
-//   top forward round r -> workspace | 12 forward stages x k, A_hat^T product, 12 inverse stages x k -> u | top inverse round (+ e1)
-// with the chunks dealt round-robin to side streams, so that the FP64-bound middle kernel of one chunk runs beside the
-// HBM-bound outer rounds of its neighbours.  d_r is only read.
-// The 8 + 8 split (n = 2^16) as a TWO-LANE software pipeline (experimental, off by default).  Lane "outer" (one stream) runs the
-// memory-bound passes of all chunks back to back — F(0), F(1), I(0), F(2), I(1), ... — lane "middle" (another stream) the
-// FP64-bound stages M(0), M(1), ... with M(c) after F(c) and I(c) after M(c) (events).  With LAMBDA_SNARK_COMMIT_MID_WAVES=4 the
-// middle kernel takes three workgroups per CU by construction and leaves a wave slot per SIMD, 34 KiB of LDS and >= 104 VGPRs,
-// so F(c+1) / I(c-1) run beside M(c) on every CU.  Round-robin streams do not give this (identical per-chunk programs fall
-// into lockstep — F beside F, M beside M); the two lanes do overlap (kernel trace in profiles/r02_commit_split_88.txt), but
-// each kernel then takes about twice as long — the outer passes, with their LDS exchange and barrier, are latency-bound at one
-// workgroup per CU — so the schedule loses (3.55 vs 3.3 ms).  tools/ubench_concurrency.hip shows the mechanism itself works.
+// TWO-LANE software pipeline of the fused commitment (LAMBDA_SNARK_COMMIT_TWO_LANE=1, either split).  Lane "outer" (one stream)
+// runs the memory-bound passes of all chunks back to back — F(0), F(1), I(0), F(2), I(1), ... — lane "middle" (another stream)
+// the FP64-bound stages M(0), M(1), ... with M(c) after F(c) and I(c) after M(c) (event rings).  The lanes own DISJOINT compute
+// units: LAMBDA_SNARK_COMMIT_OUTER_CUS = o gives the outer lane o CUs of every XCD and the middle lane the other 32 - o
+// (hipExtStreamCreateWithCUMask; mask bit = cu * 8 + xcd on this part, tools/ubench_cumask.hip), so the streaming passes and the
+// FP64 stage neither queue behind each other for wave slots nor share a register file.  o = 0: unmasked lanes (round-robin
+// placement: every kernel then takes about twice its stand-alone time, profiles/r02_commit_split_88.txt).
+static void ensure_lanes(const LweContext& c, int outer_cus) {
+    if (c.lane[0] && c.lane_outer_cus == outer_cus) return;
+    for (int i = 0; i < 2; ++i)
+        if (c.lane[i]) { LSR_HIP(hipStreamSynchronize(c.lane[i])); LSR_HIP(hipStreamDestroy(c.lane[i])); c.lane[i] = nullptr; }
+    if (outer_cus <= 0) {
+        for (int i = 0; i < 2; ++i) LSR_HIP(hipStreamCreateWithFlags(&c.lane[i], hipStreamNonBlocking));
+    } else {
+        hipDeviceProp_t prop;
+        LSR_HIP(hipGetDeviceProperties(&prop, c.ntt->device));
+        constexpr int kXcds = 8;                                       // gfx950: 8 XCDs
+        const int per_xcd = prop.multiProcessorCount / kXcds;
+        const int o = std::min(outer_cus, per_xcd - 1);
+        const int words = (prop.multiProcessorCount + 31) / 32;
+        std::vector<uint32_t> outer_mask(words, 0), middle_mask(words, 0);
+        for (int cu = 0; cu < per_xcd; ++cu)
+            for (int x = 0; x < kXcds; ++x) {
+                const int bit = cu * kXcds + x;
+                (cu < o ? outer_mask : middle_mask)[bit / 32] |= 1u << (bit % 32);
+            }
+        LSR_HIP(hipExtStreamCreateWithCUMask(&c.lane[0], (uint32_t)words, outer_mask.data()));
+        LSR_HIP(hipExtStreamCreateWithCUMask(&c.lane[1], (uint32_t)words, middle_mask.data()));
+    }
+    c.lane_outer_cus = outer_cus;
+}
+
 static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s,
-                                 const uint64_t* d_keys) {
+                                 const uint64_t* d_keys, bool split88) {
     const uint32_t k = c.k;
     const size_t vec_words = (size_t)k << c.logn;
     const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_CHUNK_MIB", 128, 1, 4096);
     const size_t chunk = std::max<size_t>(1, (chunk_mib << 20) / (vec_words * 8));
     const size_t chunks = (batch + chunk - 1) / chunk;
-    while (c.n_side < 2) {
-        LSR_HIP(hipStreamCreateWithFlags(&c.side[c.n_side], hipStreamNonBlocking));
-        LSR_HIP(hipEventCreateWithFlags(&c.ev_join[c.n_side], hipEventDisableTiming));
-        ++c.n_side;
-    }
+    ensure_lanes(c, env_int("LAMBDA_SNARK_COMMIT_OUTER_CUS", 0, 0, 31));
     if (!c.ev_fork) LSR_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
     for (int i = 0; i < LweContext::kRing; ++i) {
         if (!c.ev_outer[i]) LSR_HIP(hipEventCreateWithFlags(&c.ev_outer[i], hipEventDisableTiming));
@@ -524,17 +545,32 @@ static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const
     if (c.ws_mid.count < slot_words * kSlots) c.ws_mid.allocate(slot_words * kSlots);
     const bool sample = !d_e1 && d_keys;
     if (sample && c.ws_e1_slots.count < slot_words * kSlots) c.ws_e1_slots.allocate(slot_words * kSlots);
-    hipStream_t outer = c.side[0], middle = c.side[1];
+    hipStream_t outer = c.lane[0], middle = c.lane[1];
     LSR_HIP(hipEventRecord(c.ev_fork, s));
     LSR_HIP(hipStreamWaitEvent(outer, c.ev_fork, 0));
     LSR_HIP(hipStreamWaitEvent(middle, c.ev_fork, 0));
     const RoundConsts<ArithF64> cs{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64};
     auto span = [&](size_t ci, size_t* first, size_t* now) { *first = ci * chunk; *now = std::min(chunk, batch - *first); };
+#ifdef LSR_LANE_TRACE   // development build (make VARIANT=trace EXTRA=-DLSR_LANE_TRACE): device timeline of the two lanes on stderr
+    struct Mark { char what; size_t chunk; hipEvent_t a, b; };
+    std::vector<Mark> marks;
+    auto mark_begin = [&](char what, size_t ci, hipStream_t st) { Mark m{what, ci, nullptr, nullptr}; LSR_HIP(hipEventCreate(&m.a)); LSR_HIP(hipEventCreate(&m.b));
+                                                                   LSR_HIP(hipEventRecord(m.a, st)); marks.push_back(m); };
+    auto mark_end = [&](hipStream_t st) { LSR_HIP(hipEventRecord(marks.back().b, st)); };
+#else
+    auto mark_begin = [&](char, size_t, hipStream_t) {};
+    auto mark_end = [&](hipStream_t) {};
+#endif
     auto forward = [&](size_t ci) {
         size_t first, now; span(ci, &first, &now);
         uint64_t* const ws = c.ws_mid.ptr + (ci % kSlots) * slot_words;
-        hipLaunchKernelGGL(cols8_forward<true>, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, ws, d_r + first * vec_words,
-                           (uint32_t)(now * k), c.ntt->mod, c.ntt->fwd_f64.ptr);
+        mark_begin('F', ci, outer);
+        if (split88)
+            hipLaunchKernelGGL(cols8_forward<true>, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, ws, d_r + first * vec_words,
+                               (uint32_t)(now * k), c.ntt->mod, c.ntt->fwd_f64.ptr);
+        else
+            launch_top_round_forward(*c.ntt, ws, d_r + first * vec_words, now * k, outer);
+        mark_end(outer);
         LSR_HIP(hipEventRecord(c.ev_outer[ci % LweContext::kRing], outer));
     };
     auto middle_stage = [&](size_t ci) {
@@ -545,20 +581,36 @@ static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const
                             c.cdf_entries, middle);
         LSR_HIP(hipStreamWaitEvent(middle, c.ev_outer[ci % LweContext::kRing], 0));
         uint64_t* const out = d_u + first * vec_words;
-        switch (k) {
-            case 1: launch_mid8<1>(c, ws, out, now, middle); break;
-            case 2: launch_mid8<2>(c, ws, out, now, middle); break;
-            case 3: launch_mid8<3>(c, ws, out, now, middle); break;
-            default: launch_mid8<4>(c, ws, out, now, middle); break;
+        mark_begin('M', ci, middle);
+        if (split88) {
+            switch (k) {
+                case 1: launch_mid8<1>(c, ws, out, now, middle); break;
+                case 2: launch_mid8<2>(c, ws, out, now, middle); break;
+                case 3: launch_mid8<3>(c, ws, out, now, middle); break;
+                default: launch_mid8<4>(c, ws, out, now, middle); break;
+            }
+        } else {
+            switch (k) {
+                case 1: launch_mid<1>(c, ws, out, now, middle); break;
+                case 2: launch_mid<2>(c, ws, out, now, middle); break;
+                case 3: launch_mid<3>(c, ws, out, now, middle); break;
+                default: launch_mid<4>(c, ws, out, now, middle); break;
+            }
         }
+        mark_end(middle);
         LSR_HIP(hipEventRecord(c.ev_middle[ci % LweContext::kRing], middle));
     };
     auto inverse = [&](size_t ci) {
         size_t first, now; span(ci, &first, &now);
         const uint64_t* blind = d_e1 ? d_e1 + first * vec_words : (sample ? c.ws_e1_slots.ptr + (ci % kSlots) * slot_words : nullptr);
         LSR_HIP(hipStreamWaitEvent(outer, c.ev_middle[ci % LweContext::kRing], 0));
-        hipLaunchKernelGGL(cols8_inverse<true>, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, d_u + first * vec_words, (uint32_t)(now * k),
-                           c.ntt->mod, c.ntt->inv_f64.ptr, cs, blind);
+        mark_begin('I', ci, outer);
+        if (split88)
+            hipLaunchKernelGGL(cols8_inverse<true>, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, d_u + first * vec_words,
+                               (uint32_t)(now * k), c.ntt->mod, c.ntt->inv_f64.ptr, cs, blind);
+        else
+            launch_top_round_inverse(*c.ntt, d_u + first * vec_words, now * k, outer, blind);
+        mark_end(outer);
     };
     // enqueue order respects the event rings (an event is re-recorded only after every wait on its previous record is enqueued)
     forward(0);
@@ -568,12 +620,26 @@ static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const
         inverse(ci);
     }
     LSR_HIP(hipGetLastError());
-    for (int i = 0; i < 2; ++i) {
-        LSR_HIP(hipEventRecord(c.ev_join[i], c.side[i]));
-        LSR_HIP(hipStreamWaitEvent(s, c.ev_join[i], 0));
+    // join: the last kernel of the outer lane is I(chunks - 1), which waited for M(chunks - 1), the last kernel of the middle lane
+    LSR_HIP(hipEventRecord(c.ev_fork, outer));
+    LSR_HIP(hipStreamWaitEvent(s, c.ev_fork, 0));
+#ifdef LSR_LANE_TRACE
+    LSR_HIP(hipStreamSynchronize(outer));
+    LSR_HIP(hipStreamSynchronize(middle));
+    for (const Mark& m : marks) {
+        float t0 = 0, t1 = 0;
+        LSR_HIP(hipEventElapsedTime(&t0, marks.front().a, m.a));
+        LSR_HIP(hipEventElapsedTime(&t1, marks.front().a, m.b));
+        std::fprintf(stderr, "lane-trace %c(%zu) %7.1f -> %7.1f us\n", m.what, m.chunk, t0 * 1e3, t1 * 1e3);
     }
+    for (const Mark& m : marks) { (void)hipEventDestroy(m.a); (void)hipEventDestroy(m.b); }
+#endif
 }
 
+// Fused pipeline (caller holds c.mutex): per chunk of witness vectors
+//   top forward round r -> workspace | 12 forward stages x k, A_hat^T product, 12 inverse stages x k -> u | top inverse round (+ e1)
+// with the chunks dealt round-robin to side streams, so that the FP64-bound middle kernel of one chunk runs beside the
+// HBM-bound outer rounds of its neighbours.  d_r is only read.
 // d_e1 == NULL && d_keys != NULL: the blinding residues of a chunk are sampled (domain 5, per-vector keys d_keys[batch][4]) into
 // a chunk-sized buffer on the chunk's stream right before its transforms — no [batch][k][n] array of e1 ever exists, and the
 // sampling of one chunk runs beside the transforms of its neighbours.
@@ -583,8 +649,8 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
     // profiles/r02_commit_split_88.txt): LAMBDA_SNARK_COMMIT_SPLIT=88 — the 8 + 8 split with the barrier-free middle stage —
     // ties with the default 4 + 12 split (3.22-3.31 ms per 1024 rank-4 vectors either way); LAMBDA_SNARK_COMMIT_TWO_LANE=1 adds
     // the two-lane schedule, which is slower today because the outer passes crawl at one workgroup per CU.
-    if (c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) == 88 && env_int("LAMBDA_SNARK_COMMIT_TWO_LANE", 0, 0, 1)) {
-        mlwe_matvec_two_lane(c, d_r, d_e1, d_u, batch, s, d_keys);
+    if (env_int("LAMBDA_SNARK_COMMIT_TWO_LANE", 0, 0, 1)) {
+        mlwe_matvec_two_lane(c, d_r, d_e1, d_u, batch, s, d_keys, c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) == 88);
         return;
     }
     const uint32_t k = c.k;

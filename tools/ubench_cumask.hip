@@ -70,6 +70,31 @@ template <int MODE> __global__ void __launch_bounds__(256) var_kernel(uint64_t* 
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const uint64_t o = v[k] * 3 + v[(k + 1) & 15]; if (MODE == 5) __builtin_nontemporal_store(o, d + idx0 + k * step); else d[idx0 + k * step] = o; }
 }
+
+// ---- section 5: what bounds the READ throughput of one CU?  loads per lane, bytes per load, waves per CU (LDS padding) ----
+template <int LOADS, int WIDE> __global__ void __launch_bounds__(256) read_kernel(const uint64_t* __restrict__ d, uint64_t* __restrict__ sink, size_t total) {
+    extern __shared__ double pad[];
+    const size_t lanes_needed = total / (LOADS * (WIDE ? 2 : 1));
+    uint64_t acc = 0;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < lanes_needed; g += (size_t)gridDim.x * 256) {
+        if (WIDE) {
+            const size_t idx0 = (g / 2048) * (2048 * 2 * LOADS) + (g % 2048) * 2;
+            u64x2 v[LOADS];
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) v[k] = __builtin_nontemporal_load((const u64x2*)(d + idx0 + (size_t)k * 4096));
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) acc += v[k].x ^ v[k].y;
+        } else {
+            const size_t idx0 = (g / 4096) * (4096 * LOADS) + (g % 4096);
+            uint64_t v[LOADS];
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) v[k] = __builtin_nontemporal_load(d + idx0 + (size_t)k * 4096);
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) acc += v[k];
+        }
+    }
+    if (acc == 0x1234567) sink[0] = acc + (uint64_t)pad[0];
+}
 __global__ void where_kernel(unsigned* out) {
     if (threadIdx.x == 0) {
         unsigned xcc, hw;
@@ -155,6 +180,29 @@ int main() {
         run(var_kernel<4>, nb, "contiguous rows 8 B r+w", 2.0 * total * 8);
         run(var_kernel<5>, nb, "strided 8 B r+w nontemporal", 2.0 * total * 8);
         run(var_kernel<6>, nb / 2, "strided 16 B r+w nontemporal", 2.0 * total * 8);
+        hipStreamDestroy(sm);
+    }
+    // (5) read throughput of 8 CUs per XCD: loads in flight per lane, load width, residency
+    {
+        const int c = 8;
+        hipStream_t sm; auto mm = mask_interleaved(32, 0, c); CK(hipExtStreamCreateWithCUMask(&sm, 8, mm.data()));
+        auto run = [&](auto kern, unsigned lds, unsigned blocks, const char* label) {
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160000);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, sm, data, (uint64_t*)out, total); hipDeviceSynchronize();
+            const double t = wall([&] { for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, sm, data, (uint64_t*)out, total); });
+            printf("  read only, %2d CUs/XCD, %-46s %.3f ms  %.0f GB/s  (%.1f GB/s per CU)\n", c, label, t, 4.0 * total * 8 / t / 1e6, 4.0 * total * 8 / t / 1e6 / (c * 8));
+        };
+        const unsigned many = 1u << 16;
+        run(read_kernel<4, 0>, 0, many, "4 x 8 B per lane, full residency");
+        run(read_kernel<8, 0>, 0, many, "8 x 8 B per lane, full residency");
+        run(read_kernel<16, 0>, 0, many, "16 x 8 B per lane, full residency");
+        run(read_kernel<32, 0>, 0, many, "32 x 8 B per lane, full residency");
+        run(read_kernel<8, 1>, 0, many, "8 x 16 B per lane, full residency");
+        run(read_kernel<16, 1>, 0, many, "16 x 16 B per lane, full residency");
+        run(read_kernel<16, 0>, 40000, many, "16 x 8 B per lane, 4 workgroups per CU (LDS pad)");
+        run(read_kernel<16, 0>, 80000, many, "16 x 8 B per lane, 2 workgroups per CU (LDS pad)");
+        run(read_kernel<16, 0>, 0, 64 * 8, "16 x 8 B per lane, persistent grid 8 WG per CU");
+        run(read_kernel<16, 1>, 0, 64 * 8, "16 x 16 B per lane, persistent grid 8 WG per CU");
         hipStreamDestroy(sm);
     }
     return 0;
