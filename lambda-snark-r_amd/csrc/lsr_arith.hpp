@@ -78,6 +78,9 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
 #define LSR_NT_LAST_PASS 1
 #endif
 constexpr int kAuxStream = LSR_NT_LAST_PASS ? 2 : 0;
+#ifndef LSR_NT_COMMIT_INPUTS            // streaming loads of arrays read exactly once: out-of-place operands, blinding residues
+#define LSR_NT_COMMIT_INPUTS 1
+#endif
 template <int AUX = 0>
 __device__ __forceinline__ uint64_t buf_load64(rsrc_t r, uint32_t lane_bytes, uint32_t const_bytes) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_bytes, (int)const_bytes, AUX);

@@ -340,15 +340,24 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
     elem v[N];
     uint64_t extra[ADD ? N : 1];
     const uint64_t* const from = (!INVERSE && add != nullptr) ? add : data;
+    // streaming policy: the last pass of an inverse transform, and operands read out of place (the caller's array is read once)
+    const bool stream_in = (LSR_NT_LAST_PASS && INVERSE && !RAW_OUT) || (LSR_NT_COMMIT_INPUTS && !INVERSE && add != nullptr);
+    if (stream_in) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        constexpr bool kStream = LSR_NT_LAST_PASS && INVERSE && !RAW_OUT;   // last pass of an inverse transform
-        const uint64_t raw = kStream ? __builtin_nontemporal_load(from + idx0 + ((size_t)k << lo)) : from[idx0 + ((size_t)k << lo)];
-        v[k] = RAW_IN ? elem_from_bits<A>(raw) : A::load(raw, p);
+        for (int k = 0; k < N; ++k) {
+            const uint64_t raw = __builtin_nontemporal_load(from + idx0 + ((size_t)k << lo));
+            v[k] = RAW_IN ? elem_from_bits<A>(raw) : A::load(raw, p);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const uint64_t raw = from[idx0 + ((size_t)k << lo)];
+            v[k] = RAW_IN ? elem_from_bits<A>(raw) : A::load(raw, p);
+        }
     }
     if constexpr (ADD) {   // the blinding residues travel with the operands, not behind the arithmetic
 #pragma unroll
-        for (int k = 0; k < N; ++k) extra[k] = add[idx0 + ((size_t)k << lo)];
+        for (int k = 0; k < N; ++k) extra[k] = LSR_NT_COMMIT_INPUTS ? __builtin_nontemporal_load(add + idx0 + ((size_t)k << lo)) : add[idx0 + ((size_t)k << lo)];
     }
     if (!INVERSE) {
 #pragma unroll
