@@ -51,7 +51,8 @@ int lsr_ntt_mul_pointwise_device(const NttContext* ctx, uint64_t* d_result, cons
                                  const uint64_t* d_b, size_t count, void* stream) LSR_NOEXCEPT;
 
 /* ---------------- Gaussian sampler: seeded / device ---------------- */
-/* sample i of object (seed, domain, index) uses ChaCha20 stream words 2i (magnitude) and 2i+1 (sign);
+/* sample i of object (seed, domain, index) uses ChaCha20 stream word i (low bit: sign; upper 63 bits: the uniform
+ * value compared with the CDT table at 63-bit precision);
  * output = two's-complement int64 like sample_gaussian. Host buffer. */
 int lsr_sample_gaussian_seeded(uint64_t* output, size_t len, double sigma, uint64_t seed, uint32_t domain,
                                uint64_t index) LSR_NOEXCEPT;

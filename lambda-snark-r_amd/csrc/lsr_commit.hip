@@ -669,7 +669,8 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
     if (c.ws_mid.count < slot_words * streams) c.ws_mid.allocate(slot_words * streams);
     const bool sample = !d_e1 && d_keys;
     const bool split88 = c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) == 88;
-    if (sample && c.ws_e1_slots.count < slot_words * streams) c.ws_e1_slots.allocate(slot_words * streams);
+    const bool slots_needed = sample && (split88 || !env_int("LAMBDA_SNARK_COMMIT_SAMPLE_IN_PASS", 1, 0, 1));
+    if (slots_needed && c.ws_e1_slots.count < slot_words * streams) c.ws_e1_slots.allocate(slot_words * streams);
     LSR_HIP(hipEventRecord(c.ev_fork, s));
     for (int i = 0; i < streams; ++i) LSR_HIP(hipStreamWaitEvent(c.side[i], c.ev_fork, 0));
     size_t index = 0;
@@ -678,7 +679,10 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
         hipStream_t st = c.side[index % streams];
         uint64_t* const ws = c.ws_mid.ptr + (index % streams) * slot_words;
         const uint64_t* blind = d_e1 ? d_e1 + first * vec_words : nullptr;
-        if (sample) {
+        // sampled blinding: in the 4 + 12 pipeline the last inverse round samples e1 itself (no array of e1 at all); the 8 + 8
+        // pipeline samples the chunk's residues into a slot first
+        const bool sample_in_pass = sample && !split88 && env_int("LAMBDA_SNARK_COMMIT_SAMPLE_IN_PASS", 1, 0, 1);
+        if (sample && !sample_in_pass) {
             uint64_t* const slot = c.ws_e1_slots.ptr + (index % streams) * slot_words;
             launch_gaussian(GaussianJob{slot, d_keys + 4 * first, 0, k, kDomE1, c.n, now * k, c.q}, c.cdf.ptr, c.cdf_entries, st);
             blind = slot;
@@ -706,7 +710,8 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
             case 3: launch_mid<3>(c, ws, out, now, st); break;
             default: launch_mid<4>(c, ws, out, now, st); break;
         }
-        launch_top_round_inverse(*c.ntt, out, now * k, st, blind);
+        if (sample_in_pass) launch_top_round_inverse_sampled(*c.ntt, out, now * k, st, BlindSampler{d_keys + 4 * first, c.cdf.ptr, c.cdf_entries, k, kDomE1});
+        else launch_top_round_inverse(*c.ntt, out, now * k, st, blind);
     }
     for (int i = 0; i < streams; ++i) {
         LSR_HIP(hipEventRecord(c.ev_join[i], c.side[i]));

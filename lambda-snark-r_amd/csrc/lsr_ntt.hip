@@ -365,6 +365,22 @@ void launch_top_round_inverse(const NttContext& c, uint64_t* data, size_t polys,
     LSR_HIP(hipGetLastError());
 }
 
+void launch_top_round_inverse_sampled(const NttContext& c, uint64_t* data, size_t polys, hipStream_t s, const BlindSampler& bs) {
+    if (!c.use_f64 || c.logn <= kTileLog) throw std::runtime_error("top-round launch: FP64 flavour, n > 4096 only");
+    const int r_top = std::max(c.logn - kTileLog, 4), lo = c.logn - r_top;
+    const size_t total = polys << c.logn;
+    const unsigned grid = static_cast<unsigned>(((total >> r_top) + kThreads - 1) / kThreads);
+    const unsigned lds = (((bs.entries + 1u) & ~1u) * 8u) + (kThreads << r_top) * 4u;       // table + [2^r][256] int32
+    const auto cs = Flavour<ArithF64>::consts(c);
+    if (r_top == 4)
+        hipLaunchKernelGGL((ntt_strided_round_sampled<ArithF64, 4, true>), dim3(grid), dim3(kThreads), lds, s, data, total, lo, c.mod, Flavour<ArithF64>::inv(c), cs, bs);
+    else if (r_top == 5)
+        hipLaunchKernelGGL((ntt_strided_round_sampled<ArithF64, 5, true>), dim3(grid), dim3(kThreads), lds, s, data, total, lo, c.mod, Flavour<ArithF64>::inv(c), cs, bs);
+    else
+        throw std::runtime_error("top-round launch: 4 or 5 top bits only");
+    LSR_HIP(hipGetLastError());
+}
+
 void launch_pointwise(const NttContext& c, uint64_t* out, const uint64_t* a, const uint64_t* b, size_t count, hipStream_t s) {
     if (!count) return;
     const size_t want = (count + kThreads - 1) / kThreads;

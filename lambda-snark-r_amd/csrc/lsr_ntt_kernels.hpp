@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "lsr_arith.hpp"
+#include "lsr_sampler.hpp"
 
 namespace lsr {
 
@@ -326,15 +327,21 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
 // 2^(R-1-j) + u for every lane of every polynomial: compile-time indices, scalar loads, no VGPRs for twiddles.
 // ADD: canonical residues `add` are added to the outputs in the final store (inverse, last pass only).
 // Forward rounds (ADD is then false): a non-null `add` is the array to READ the operands from (out-of-place first pass).
-template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT, bool ADD>
-__global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
-                                                                const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
-                                                                const uint64_t* __restrict__ add) {
+// SAMPLE (with ADD): the blinding residues are not read from `add` but SAMPLED here, in the pass that consumes them — the CDT
+// Gaussian of lsr_sampler.hpp, object = polynomial (key bs.keys[4 (poly / components)], stream index poly % components).  A
+// workgroup owns 256 columns x 2^R rows of one polynomial = 2^R * 32 ChaCha blocks of 8 consecutive coefficients, 2^R / 8 blocks
+// per lane; the samples change hands through LDS ([row][column] int32).  The operand loads are issued first and are in flight
+// under the cipher work, so the integer-bound sampler and the memory-bound round share one pass (and e1 never exists in memory).
+template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT, bool ADD, bool SAMPLE>
+__device__ __forceinline__ void strided_round_body(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
+                                                   const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
+                                                   const uint64_t* __restrict__ add, const BlindSampler& bs) {
     static_assert(!ADD || (INVERSE && !RAW_OUT), "the fused add belongs to the last inverse pass");
+    static_assert(!SAMPLE || (ADD && R >= 3), "sampling replaces the read of the blinding residues; 2^R / 8 blocks per lane");
     using elem = typename A::elem;
     constexpr int N = 1 << R;
     const size_t group = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    if (group >= (total >> R)) return;
+    if (group >= (total >> R)) return;          // whole workgroups: total >> R is a multiple of kThreads (2^lo >= 512)
     const size_t low = group & (((size_t)1 << lo) - 1);
     const size_t idx0 = ((group >> lo) << (lo + R)) | low;
     elem v[N];
@@ -355,7 +362,37 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
             v[k] = RAW_IN ? elem_from_bits<A>(raw) : A::load(raw, p);
         }
     }
-    if constexpr (ADD) {   // the blinding residues travel with the operands, not behind the arithmetic
+    if constexpr (SAMPLE) {
+        extern __shared__ uint64_t lds_words[];
+        uint64_t* const cdf63 = lds_words;
+        int32_t* const tile = reinterpret_cast<int32_t*>(lds_words + ((bs.entries + 1u) & ~1u));
+        for (uint32_t i = threadIdx.x; i < bs.entries; i += kThreads) cdf63[i] = bs.cdf[i] >> 1;
+        __syncthreads();
+        const size_t g0 = (size_t)blockIdx.x * kThreads;               // workgroup-uniform: polynomial and first column
+        const uint32_t poly = (uint32_t)(g0 >> lo), low0 = (uint32_t)(g0 & (((size_t)1 << lo) - 1));
+        const uint64_t* const key = bs.keys + 4 * (size_t)(poly / bs.components);
+#pragma unroll 1
+        for (int h = 0; h < N / 8; ++h) {
+            const uint32_t b = (uint32_t)h * kThreads + threadIdx.x, row = b >> 5, cb = b & 31u;
+            uint64_t w[8], u[8];
+            stream_block(key, bs.domain, poly % bs.components, (((row << lo) + low0) >> 3) + cb, w);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) u[i] = w[i] >> 1;
+            uint32_t magnitude[8];
+            cdt_scan<8>(cdf63, bs.entries, u, magnitude);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int32_t m = (int32_t)magnitude[i], sign = (int32_t)(w[i] & 1ull);
+                tile[row * kThreads + cb * 8 + i] = sign ? -m : m;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int32_t e = tile[k * kThreads + threadIdx.x];
+            extra[k] = e < 0 ? p.q - (uint64_t)(-e) : (uint64_t)e;
+        }
+    } else if constexpr (ADD) {   // the blinding residues travel with the operands, not behind the arithmetic
 #pragma unroll
         for (int k = 0; k < N; ++k) extra[k] = LSR_NT_COMMIT_INPUTS ? __builtin_nontemporal_load(add + idx0 + ((size_t)k << lo)) : add[idx0 + ((size_t)k << lo)];
     }
@@ -407,6 +444,20 @@ __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restri
         if constexpr (LSR_NT_LAST_PASS && INVERSE && !RAW_OUT) __builtin_nontemporal_store(out, data + gi);
         else data[gi] = out;
     }
+}
+
+template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT, bool ADD>
+__global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
+                                                                const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
+                                                                const uint64_t* __restrict__ add) {
+    strided_round_body<A, R, INVERSE, RAW_IN, RAW_OUT, ADD, false>(data, total, lo, p, tw, cs, add, BlindSampler{});
+}
+
+// last pass of an inverse transform with the blinding residues sampled in place (dynamic LDS: table + 2^R x 256 int32)
+template <class A, int R, bool RAW_IN>
+__global__ void __launch_bounds__(kThreads) ntt_strided_round_sampled(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
+                                                                        const typename A::twid* __restrict__ tw, RoundConsts<A> cs, BlindSampler bs) {
+    strided_round_body<A, R, true, RAW_IN, false, true, true>(data, total, lo, p, tw, cs, nullptr, bs);
 }
 
 // ---- pointwise product (ntt.cpp:106-119) ------------------------------------------------------------

@@ -116,6 +116,9 @@ void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inve
 // to `dst` (may alias); inverse turns raw elements into canonical residues (+ optional canonical `add`), in place
 void launch_top_round_forward(const NttContext& ctx, uint64_t* d_dst, const uint64_t* d_src, size_t polys, hipStream_t stream);
 void launch_top_round_inverse(const NttContext& ctx, uint64_t* d_data, size_t polys, hipStream_t stream, const uint64_t* add);
+// the same round with the added residues sampled in the pass (CDT Gaussian per polynomial, lsr_sampler.hpp) instead of read
+struct BlindSampler;
+void launch_top_round_inverse_sampled(const NttContext& ctx, uint64_t* d_data, size_t polys, hipStream_t stream, const BlindSampler& sampler);
 void launch_pointwise(const NttContext& ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t count,
                       hipStream_t stream);
 // out[b][i] = in[b][bitrev_logn(i)] (out != in)

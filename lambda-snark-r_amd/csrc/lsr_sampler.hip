@@ -14,12 +14,12 @@ namespace lsr {
 
 constexpr int kSamplerThreads = 256;
 
-// One lane = one ChaCha block = four samples.  The CDT table sits in LDS.
+// One lane = one ChaCha block = eight samples.  The CDT table sits in LDS at 63-bit precision (lsr_sampler.hpp).
 __global__ void __launch_bounds__(kSamplerThreads) gaussian_kernel(GaussianJob job, const uint64_t* __restrict__ cdf_global, uint32_t entries) {
     extern __shared__ uint64_t cdf[];
-    for (uint32_t i = threadIdx.x; i < entries; i += kSamplerThreads) cdf[i] = cdf_global[i];
+    for (uint32_t i = threadIdx.x; i < entries; i += kSamplerThreads) cdf[i] = cdf_global[i] >> 1;
     __syncthreads();
-    const uint64_t blocks_per_object = (job.samples + 3) >> 2;
+    const uint64_t blocks_per_object = (job.samples + kSamplesPerBlock - 1) / kSamplesPerBlock;
     const uint64_t gid = (uint64_t)blockIdx.x * kSamplerThreads + threadIdx.x;
     if (gid >= blocks_per_object * job.objects) return;
     const uint64_t object = gid / blocks_per_object;
@@ -27,20 +27,17 @@ __global__ void __launch_bounds__(kSamplerThreads) gaussian_kernel(GaussianJob j
     const uint64_t index = job.index_base + object % job.components;
     uint64_t w[8];
     stream_block(job.keys + 4 * (object / job.components), job.domain, index, (uint32_t)block, w);
-    uint64_t* dst = job.out + object * job.samples + block * 4;
-    const uint64_t left = job.samples - block * 4;
-    const uint64_t u[4] = {w[0], w[2], w[4], w[6]};
-    uint32_t magnitude[4];
-    cdt_scan<4>(cdf, entries, u, magnitude);
+    uint64_t* dst = job.out + object * job.samples + block * kSamplesPerBlock;
+    const uint64_t left = job.samples - block * kSamplesPerBlock;
+    uint64_t u[8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 8; ++s) u[s] = w[s] >> 1;
+    uint32_t magnitude[8];
+    cdt_scan<8>(cdf, entries, u, magnitude);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
         if ((uint64_t)s >= left) break;
-        const uint64_t m = magnitude[s];
-        const uint64_t sign = (w[2 * s + 1] & 1ull) & (uint64_t)(m != 0);      // branch-free sign (utils.cpp:114-120)
-        uint64_t value;
-        if (job.q) value = sign ? job.q - m : m;
-        else value = (m ^ (0ull - sign)) + sign;                                // two's complement of m when sign is set
-        dst[s] = value;
+        dst[s] = gaussian_value(magnitude[s], w[s], job.q);
     }
 }
 
@@ -77,7 +74,7 @@ __global__ void __launch_bounds__(kSamplerThreads) splitmix_kernel(uint64_t* __r
 }
 
 void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream) {
-    const uint64_t lanes = ((job.samples + 3) >> 2) * job.objects;
+    const uint64_t lanes = ((job.samples + kSamplesPerBlock - 1) / kSamplesPerBlock) * job.objects;
     if (!lanes) return;
     const unsigned grid = static_cast<unsigned>((lanes + kSamplerThreads - 1) / kSamplerThreads);
     hipLaunchKernelGGL(gaussian_kernel, dim3(grid), dim3(kSamplerThreads), entries * sizeof(uint64_t), stream, job, d_cdf, entries);
@@ -97,7 +94,7 @@ void launch_uniform(uint64_t* out, const uint64_t* d_keys, uint64_t index_base, 
 static int sample_to_host(uint64_t* output, size_t len, double sigma, uint64_t seed, uint32_t domain, uint64_t index) {
     const std::vector<uint64_t> table = gaussian_cdf(sigma);
     if (table.empty() || table.size() > 8000) throw std::runtime_error("sigma out of the supported range (table must fit LDS)");
-    if ((len + 3) / 4 > 0xFFFFFFFFull) throw std::runtime_error("len exceeds one stream (2^34 samples)");
+    if ((len + 7) / 8 > 0xFFFFFFFFull) throw std::runtime_error("len exceeds one stream (2^35 samples)");
     if (visible_device_count() <= 0) throw std::runtime_error("no HIP device visible — no CPU fallback");
     DeviceGuard guard(default_device());
     DeviceBuffer<uint64_t> d_cdf, d_key, d_out(len);

@@ -4,7 +4,10 @@
 // std::random_device: one compared against the CDT table (first k with cdf[k] >= u), one whose low bit is
 // the sign.  Here the words come from a counter-based ChaCha20 stream so that a seed reproduces the
 // output on any device: object (key, domain, index) owns a stream; 64-bit word w of it is ChaCha block
-// w/8, 32-bit words 2(w%8) (low half) and 2(w%8)+1 (high half); sample i uses words 2i and 2i+1.
+// w/8, 32-bit words 2(w%8) (low half) and 2(w%8)+1 (high half).  Sample i uses ONE word, word i: its low
+// bit is the sign, its upper 63 bits are the uniform value compared with the table at 63-bit precision
+// (first k with cdf[k] >> 1 >= word >> 1) — half the cipher work of spending a second word on one sign
+// bit; the table itself is only accurate to about 2^-63 (long double accumulation, utils.cpp:26-75).
 //   key   = 256 bits from the key schedule of lsr_keys.hpp (per context / per commitment), or the expansion
 //           { seed_lo, seed_hi, "LSR1", "STRM", 0, 0, 0, 0 } of a raw 64-bit test seed
 //   nonce = { domain, index_lo, index_hi }          counter = block number
@@ -51,20 +54,29 @@ __device__ __forceinline__ void stream_block(const uint64_t* __restrict__ key4, 
     for (int j = 0; j < 8; ++j) w[j] = (uint64_t)(x[2 * j] + init[2 * j]) | ((uint64_t)(x[2 * j + 1] + init[2 * j + 1]) << 32);
 }
 
-// Magnitudes of COUNT samples at once: first k with cdf[k] >= u[s] (cdf non-decreasing, cdf[entries-1] == 2^64-1) — the value the
-// reference's scan selects (utils.cpp:101-108) — computed the way the reference computes it: a branch-free pass over the
-// WHOLE table, count += (cdf[k] < u).  Every lane reads the same LDS word per step (a broadcast), so neither the
-// instruction stream nor the LDS access pattern depends on the secret uniform words.
+// Magnitudes of COUNT samples at once: first k with cdf63[k] >= u[s] (cdf63 = table >> 1, non-decreasing, last entry 2^63 - 1;
+// u = stream word >> 1) — the value the reference's scan selects (utils.cpp:101-108) — computed the way the reference computes
+// it: a branch-free pass over the WHOLE table, count += (cdf63[k] < u).  Every lane reads the same LDS word per step (a
+// broadcast), so neither the instruction stream nor the LDS access pattern depends on the secret uniform words.
 template <int COUNT>
-__device__ __forceinline__ void cdt_scan(const uint64_t* cdf, uint32_t entries, const uint64_t (&u)[COUNT], uint32_t (&magnitude)[COUNT]) {
+__device__ __forceinline__ void cdt_scan(const uint64_t* cdf63, uint32_t entries, const uint64_t (&u)[COUNT], uint32_t (&magnitude)[COUNT]) {
 #pragma unroll
     for (int s = 0; s < COUNT; ++s) magnitude[s] = 0;
-    for (uint32_t k = 0; k + 1 < entries; ++k) {      // the last entry is 2^64 - 1: never below u
-        const uint64_t c = cdf[k];
+    for (uint32_t k = 0; k + 1 < entries; ++k) {      // the last entry is 2^63 - 1: never below u
+        const uint64_t c = cdf63[k];
 #pragma unroll
         for (int s = 0; s < COUNT; ++s) magnitude[s] += (c < u[s]) ? 1u : 0u;
     }
 }
+
+// sign applied to a magnitude without a branch (utils.cpp:114-120): residue in [0,q), or two's-complement int64 when q == 0
+__device__ __forceinline__ uint64_t gaussian_value(uint32_t magnitude, uint64_t word, uint64_t q) {
+    const uint64_t m = magnitude;
+    const uint64_t sign = (word & 1ull) & (uint64_t)(m != 0);
+    return q ? (sign ? q - m : m) : (m ^ (0ull - sign)) + sign;
+}
+
+constexpr int kSamplesPerBlock = 8;     // one ChaCha20 block = eight 64-bit words = eight samples
 
 struct GaussianJob {
     uint64_t* out;            // [objects][samples]
@@ -75,6 +87,13 @@ struct GaussianJob {
     uint64_t samples;         // per object
     uint64_t objects;
     uint64_t q;               // 0: two's-complement int64 (utils.cpp:142); else residue in [0,q)
+};
+
+// the same sampler run INSIDE the pass that consumes the samples (ntt_strided_round_sampled, lsr_ntt_kernels.hpp): object = polynomial
+struct BlindSampler {
+    const uint64_t* keys = nullptr;     // [objects / components][4]
+    const uint64_t* cdf = nullptr;      // CDT table (64-bit thresholds)
+    uint32_t entries = 0, components = 1, domain = 0;
 };
 
 void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream);

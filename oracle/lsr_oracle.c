@@ -435,6 +435,24 @@ static int64_t cdt_pick(const uint64_t* cdf, size_t entries, uint64_t u, uint64_
     return sign ? -mag : mag;
 }
 
+/* the library's seeded form: ONE stream word per sample — low bit = sign, upper 63 bits against the table at 63-bit
+ * precision (first k with cdf[k] >> 1 >= word >> 1); same scan, same sign rule */
+static int64_t cdt_pick_word(const uint64_t* cdf, size_t entries, uint64_t word) {
+    uint32_t chosen = (uint32_t)(entries - 1);
+    uint64_t found = 0;
+    const uint64_t u = word >> 1;
+    for (size_t k = 0; k < entries; ++k) {
+        uint64_t ge = (uint64_t)((cdf[k] >> 1) >= u);
+        uint64_t sel = ge & (1ull ^ found);
+        uint32_t m32 = (uint32_t)(-(int32_t)sel);
+        chosen = (chosen & ~m32) | ((uint32_t)k & m32);
+        found |= sel;
+    }
+    uint64_t sign = (word & 1ull) & (uint64_t)(chosen != 0);
+    int64_t mag = (int64_t)chosen;
+    return sign ? -mag : mag;
+}
+
 int oracle_sample_gaussian(uint64_t* out, size_t len, double sigma) {
     if (!out || len == 0 || !(sigma > 0.0) || !isfinite(sigma)) return -1;   /* utils.cpp:133 */
     uint64_t cdf[4096];
@@ -458,8 +476,8 @@ static int sample_gaussian_keyed(uint64_t* out, size_t len, double sigma, const 
     if (!entries) return -1;
     uint64_t w[8];
     for (size_t i = 0; i < len; ++i) {
-        if ((i & 3) == 0) key_block(key, domain, index, (uint32_t)(i >> 2), w);
-        out[i] = (uint64_t)cdt_pick(cdf, entries, w[2 * (i & 3)], w[2 * (i & 3) + 1]);
+        if ((i & 7) == 0) key_block(key, domain, index, (uint32_t)(i >> 3), w);
+        out[i] = (uint64_t)cdt_pick_word(cdf, entries, w[i & 7]);
     }
     return 0;
 }

@@ -79,7 +79,7 @@ void oracle_stream_words(uint64_t seed, uint32_t domain, uint64_t index, uint64_
 size_t oracle_gaussian_cdf(double sigma, uint64_t* cdf, size_t cap);
 /* reference-equivalent sampler on fresh entropy (std::random_device analogue: /dev/urandom) */
 int oracle_sample_gaussian(uint64_t* out, size_t len, double sigma);
-/* seeded variant: sample i uses stream words 2i (magnitude) and 2i+1 (sign bit) */
+/* seeded variant: sample i uses stream word i — low bit = sign, upper 63 bits against the table >> 1 */
 int oracle_sample_gaussian_seeded(uint64_t* out, size_t len, double sigma, uint64_t seed, uint32_t domain, uint64_t index);
 
 /* ---------- Module-LWE commitment (definition: DESIGN.md §commitment) ---------- */
