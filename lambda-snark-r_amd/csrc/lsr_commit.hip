@@ -397,7 +397,7 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
         DeviceBuffer<uint64_t> pub_key, sec_key, e_hat(kn);
         pub_key.upload(key_words(c->keys.pub));
         sec_key.upload(key_words(c->keys.sec));
-        hipStream_t s = c->ntt->stream;
+        hipStream_t s = work_stream(*c->ntt);
         launch_uniform(c->a_hat.ptr, pub_key.ptr, 0, k * k, kDomA, n, (uint64_t)k * k, q, s);
         launch_gaussian(GaussianJob{c->s_hat.ptr, sec_key.ptr, 0, k, kDomS, n, k, q}, c->cdf.ptr, c->cdf_entries, s);
         launch_gaussian(GaussianJob{e_hat.ptr, sec_key.ptr, 0, k, kDomE, n, k, q}, c->cdf.ptr, c->cdf_entries, s);
@@ -502,12 +502,40 @@ static void launch_mid8(const LweContext& c, const uint64_t* ws, uint64_t* d_u, 
 // (hipExtStreamCreateWithCUMask; mask bit = cu * 8 + xcd on this part, tools/ubench_cumask.hip), so the streaming passes and the
 // FP64 stage neither queue behind each other for wave slots nor share a register file.  o = 0: unmasked lanes (round-robin
 // placement: every kernel then takes about twice its stand-alone time, profiles/r02_commit_split_88.txt).
+// Side streams that do not share a hardware queue.  Plain streams are multiplexed onto a small pool of hardware queues (four by
+// default, the least-used one at creation) and two streams of one context can land on the same queue — their kernels then run
+// strictly one after the other and the round-robin chunk schedule overlaps nothing (seen in bench.py: every commit kernel on one
+// queue, 3.44 ms per 1024 vectors instead of 3.2).  The runtime keeps one queue pool per stream priority, so side streams of
+// alternating priority (LAMBDA_SNARK_COMMIT_STREAM_MODE=1) cannot share a queue; mode 2: streams with an all-CU mask
+// (a dedicated queue each; measured slower); mode 0, default: plain streams — the pipeline keeps its own stream count at one.
+static hipStream_t create_side_stream(int device, int ordinal) {
+    hipStream_t st = nullptr;
+    const int mode = env_int("LAMBDA_SNARK_COMMIT_STREAM_MODE", 0, 0, 2);
+    if (mode == 1) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
+            hipStreamCreateWithPriority(&st, hipStreamNonBlocking, (ordinal & 1) ? greatest : (least + greatest) / 2) == hipSuccess)
+            return st;
+        (void)hipGetLastError();
+    } else if (mode == 2) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+            std::vector<uint32_t> all((prop.multiProcessorCount + 31) / 32, 0);
+            for (int cu = 0; cu < prop.multiProcessorCount; ++cu) all[cu / 32] |= 1u << (cu % 32);
+            if (hipExtStreamCreateWithCUMask(&st, (uint32_t)all.size(), all.data()) == hipSuccess) return st;
+            (void)hipGetLastError();
+        }
+    }
+    LSR_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return st;
+}
+
 static void ensure_lanes(const LweContext& c, int outer_cus) {
     if (c.lane[0] && c.lane_outer_cus == outer_cus) return;
     for (int i = 0; i < 2; ++i)
         if (c.lane[i]) { LSR_HIP(hipStreamSynchronize(c.lane[i])); LSR_HIP(hipStreamDestroy(c.lane[i])); c.lane[i] = nullptr; }
     if (outer_cus <= 0) {
-        for (int i = 0; i < 2; ++i) LSR_HIP(hipStreamCreateWithFlags(&c.lane[i], hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) c.lane[i] = create_side_stream(c.ntt->device, i);
     } else {
         hipDeviceProp_t prop;
         LSR_HIP(hipGetDeviceProperties(&prop, c.ntt->device));
@@ -659,24 +687,27 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
     const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_CHUNK_MIB", 128, 1, 4096);
     const size_t chunk = std::max<size_t>(1, (chunk_mib << 20) / (vec_words * 8));
     const int streams = static_cast<int>(std::min<size_t>((size_t)want, (batch + chunk - 1) / chunk));
-    while (c.n_side < streams) {
-        LSR_HIP(hipStreamCreateWithFlags(&c.side[c.n_side], hipStreamNonBlocking));
+    // lane 0 is the caller's stream itself, lanes 1.. are side streams: every stream a process opens competes for the runtime's few
+    // hardware queues (four by default), and two lanes that land on one queue overlap nothing
+    while (c.n_side < streams - 1) {
+        c.side[c.n_side] = create_side_stream(c.ntt->device, c.n_side);
         LSR_HIP(hipEventCreateWithFlags(&c.ev_join[c.n_side], hipEventDisableTiming));
         ++c.n_side;
     }
     if (!c.ev_fork) LSR_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+    auto lane = [&](size_t i) { return i == 0 ? s : c.side[i - 1]; };
     const size_t slot_words = std::min(chunk, batch) * vec_words;
     if (c.ws_mid.count < slot_words * streams) c.ws_mid.allocate(slot_words * streams);
     const bool sample = !d_e1 && d_keys;
     const bool split88 = c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) == 88;
     const bool slots_needed = sample && (split88 || !env_int("LAMBDA_SNARK_COMMIT_SAMPLE_IN_PASS", 1, 0, 1));
     if (slots_needed && c.ws_e1_slots.count < slot_words * streams) c.ws_e1_slots.allocate(slot_words * streams);
-    LSR_HIP(hipEventRecord(c.ev_fork, s));
-    for (int i = 0; i < streams; ++i) LSR_HIP(hipStreamWaitEvent(c.side[i], c.ev_fork, 0));
+    if (streams > 1) LSR_HIP(hipEventRecord(c.ev_fork, s));
+    for (int i = 1; i < streams; ++i) LSR_HIP(hipStreamWaitEvent(lane(i), c.ev_fork, 0));
     size_t index = 0;
     for (size_t first = 0; first < batch; first += chunk, ++index) {
         const size_t now = std::min(chunk, batch - first);
-        hipStream_t st = c.side[index % streams];
+        hipStream_t st = lane(index % streams);
         uint64_t* const ws = c.ws_mid.ptr + (index % streams) * slot_words;
         const uint64_t* blind = d_e1 ? d_e1 + first * vec_words : nullptr;
         // sampled blinding: in the 4 + 12 pipeline the last inverse round samples e1 itself (no array of e1 at all); the 8 + 8
@@ -713,9 +744,9 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
         if (sample_in_pass) launch_top_round_inverse_sampled(*c.ntt, out, now * k, st, BlindSampler{d_keys + 4 * first, c.cdf.ptr, c.cdf_entries, k, kDomE1});
         else launch_top_round_inverse(*c.ntt, out, now * k, st, blind);
     }
-    for (int i = 0; i < streams; ++i) {
-        LSR_HIP(hipEventRecord(c.ev_join[i], c.side[i]));
-        LSR_HIP(hipStreamWaitEvent(s, c.ev_join[i], 0));
+    for (int i = 1; i < streams; ++i) {
+        LSR_HIP(hipEventRecord(c.ev_join[i - 1], lane(i)));
+        LSR_HIP(hipStreamWaitEvent(s, c.ev_join[i - 1], 0));
     }
 }
 
@@ -757,7 +788,7 @@ static LweCommitment* new_commitment(size_t words) {
 static void commit_compute(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds) {
     const uint32_t n = c.n, k = c.k;
     ensure_workspace(c, batch);
-    hipStream_t s = c.ntt->stream;
+    hipStream_t s = work_stream(*c.ntt);
     // host prep: the per-commitment stream keys (lsr_keys.hpp): seed == 0 => 256 bits of fresh entropy (commitment.h:52), else
     // PRF(seed, context id, embedded message) — a reused seed never repeats the blinding across messages or contexts
     std::vector<uint64_t>& key_host = c.ws_key_host;
@@ -828,7 +859,7 @@ static void commit_chunk_flat(const LweContext& c, const uint64_t* messages, siz
                               bool to_device) {
     const uint64_t n = c.n, kn = (uint64_t)c.k * c.n, words = kHeaderWords + kn + n;
     commit_compute(c, messages, msg_len, batch, seeds);
-    hipStream_t s = c.ntt->stream;
+    hipStream_t s = work_stream(*c.ntt);
     DeviceBuffer<uint64_t> packed;
     uint64_t* rows = out_words;
     if (!to_device) {
@@ -846,7 +877,7 @@ static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t m
     const uint32_t n = c.n, k = c.k;
     const size_t kn = (size_t)k * n;
     commit_compute(c, messages, msg_len, batch, seeds);
-    hipStream_t s = c.ntt->stream;
+    hipStream_t s = work_stream(*c.ntt);
     // gather: u and v of the whole chunk come back in two bulk copies into pinned memory; the per-commitment arrays
     // (which the ABI wants as separate new[] allocations, commitment.cpp:50-57) are filled from there by a few threads
     const size_t words = kHeaderWords + kn + n;
@@ -919,7 +950,7 @@ static int verify_opening(const LweContext& c, const LweCommitment* cm, const ui
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
     ensure_workspace(c, 1);
-    hipStream_t s = c.ntt->stream;
+    hipStream_t s = work_stream(*c.ntt);
     LSR_HIP(hipMemcpyAsync(c.ws_u.ptr, body, kn * 8, hipMemcpyHostToDevice, s));
     LSR_HIP(hipMemcpyAsync(c.ws_v.ptr, body + kn, (size_t)n * 8, hipMemcpyHostToDevice, s));
     LSR_HIP(hipMemcpyAsync(c.ws_dm.ptr, message, msg_len * 8, hipMemcpyHostToDevice, s));
@@ -948,7 +979,7 @@ static void verify_bodies(const LweContext& c, const std::vector<const uint64_t*
     const size_t kn = (size_t)k * n, body_words = kn + n;
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
-    hipStream_t s = c.ntt->stream;
+    hipStream_t s = work_stream(*c.ntt);
     const size_t per_opening = (4 * (size_t)k + 4) * n * 8;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(live.size(), (1ull << 30) / per_opening));
     ensure_workspace(c, chunk);
@@ -1026,7 +1057,7 @@ static void verify_opening_batch_flat(const LweContext& c, const uint64_t* words
     }
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
-    hipStream_t s = c.ntt->stream;
+    hipStream_t s = work_stream(*c.ntt);
     const size_t per_opening = (4 * (size_t)k + 5) * n * 8;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(count, (1ull << 30) / per_opening));
     ensure_workspace(c, chunk);
@@ -1063,7 +1094,7 @@ static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** 
     const size_t body_words = (size_t)(c.k + 1) * c.n;
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
-    hipStream_t s = c.ntt->stream;
+    hipStream_t s = work_stream(*c.ntt);
     // bodies are gathered `group` at a time (<= 64 MiB) in pinned memory, uploaded in one copy and folded in by one kernel
     const size_t group = std::max<size_t>(1, std::min<size_t>(count, (size_t(64) << 20) / (body_words * 8)));
     DeviceBuffer<uint64_t> acc(body_words), terms(group * body_words), d_coeffs(group);
@@ -1418,7 +1449,7 @@ int lsr_mlwe_matvec_batch_sharded(LweContext* const* ctxs, int shards, uint64_t*
         const LweContext& c = *ctxs[g];
         std::lock_guard<std::mutex> lock(c.mutex);
         lsr::DeviceBuffer<uint64_t> d_u(count * vec_words);
-        hipStream_t s = c.ntt->stream;
+        hipStream_t s = lsr::work_stream(*c.ntt);
         const auto t0 = std::chrono::steady_clock::now();
         lsr::mlwe_matvec_device(c, d_r[g], d_e1[g], d_u.ptr, count, s, true);
         LSR_HIP(hipStreamSynchronize(s));

@@ -122,7 +122,6 @@ static NttContext* build_context(const char* where, uint64_t q, uint32_t n, int 
             ctx->w_last_scaled_u64 = ShoupOperand{w_last_scaled, shoup_quotient(w_last_scaled, q)};
         }
         ctx->staging.allocate(3ull * n);
-        LSR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     } catch (const std::exception& e) {
         set_last_error(std::string(where) + ": " + e.what());
         std::fprintf(stderr, "lambda_snark_core: %s failed: %s\n", where, e.what());
@@ -154,6 +153,15 @@ NttContext* create_cyclic_ntt_context(uint64_t q, uint32_t n, uint64_t omega, in
         return nullptr;
     }
     return build_context("lsr_cyclic_ntt_context_create", q, n, logn, device, build_cyclic_twiddles(q, n, logn, omega), true);
+}
+
+hipStream_t work_stream(const NttContext& c) {
+    std::lock_guard<std::mutex> lock(c.stream_mutex);
+    if (!c.stream) {
+        DeviceGuard guard(c.device);
+        LSR_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    }
+    return c.stream;
 }
 
 void destroy_ntt_context(NttContext* ctx) {
@@ -404,21 +412,21 @@ static void host_ntt(const NttContext& c, uint64_t* polys, size_t batch, bool in
     const size_t n = c.degree;
     if (batch == 1) {
         std::lock_guard<std::mutex> lock(c.staging_mutex);
-        LSR_HIP(hipMemcpyAsync(c.staging.ptr, polys, n * 8, hipMemcpyHostToDevice, c.stream));
-        launch_ntt(c, c.staging.ptr, 1, inverse, c.stream);
-        LSR_HIP(hipMemcpyAsync(polys, c.staging.ptr, n * 8, hipMemcpyDeviceToHost, c.stream));
-        LSR_HIP(hipStreamSynchronize(c.stream));
+        LSR_HIP(hipMemcpyAsync(c.staging.ptr, polys, n * 8, hipMemcpyHostToDevice, work_stream(c)));
+        launch_ntt(c, c.staging.ptr, 1, inverse, work_stream(c));
+        LSR_HIP(hipMemcpyAsync(polys, c.staging.ptr, n * 8, hipMemcpyDeviceToHost, work_stream(c)));
+        LSR_HIP(hipStreamSynchronize(work_stream(c)));
         return;
     }
     const size_t chunk_polys = std::max<size_t>(1, std::min<size_t>(batch, (512ull << 20) / (n * 8)));
     DeviceBuffer<uint64_t> buf(chunk_polys * n);
-    std::lock_guard<std::mutex> lock(c.staging_mutex);   // serialises use of c.stream
+    std::lock_guard<std::mutex> lock(c.staging_mutex);   // serialises use of work_stream(c)
     for (size_t done = 0; done < batch; done += chunk_polys) {
         const size_t now = std::min(chunk_polys, batch - done);
-        LSR_HIP(hipMemcpyAsync(buf.ptr, polys + done * n, now * n * 8, hipMemcpyHostToDevice, c.stream));
-        launch_ntt(c, buf.ptr, now, inverse, c.stream);
-        LSR_HIP(hipMemcpyAsync(polys + done * n, buf.ptr, now * n * 8, hipMemcpyDeviceToHost, c.stream));
-        LSR_HIP(hipStreamSynchronize(c.stream));
+        LSR_HIP(hipMemcpyAsync(buf.ptr, polys + done * n, now * n * 8, hipMemcpyHostToDevice, work_stream(c)));
+        launch_ntt(c, buf.ptr, now, inverse, work_stream(c));
+        LSR_HIP(hipMemcpyAsync(polys + done * n, buf.ptr, now * n * 8, hipMemcpyDeviceToHost, work_stream(c)));
+        LSR_HIP(hipStreamSynchronize(work_stream(c)));
     }
 }
 
@@ -435,11 +443,11 @@ static void host_pointwise(const NttContext& c, uint64_t* result, const uint64_t
     uint64_t* da = base;
     uint64_t* db = base + count;
     uint64_t* dr = base + 2 * count;
-    LSR_HIP(hipMemcpyAsync(da, a, count * 8, hipMemcpyHostToDevice, c.stream));
-    LSR_HIP(hipMemcpyAsync(db, b, count * 8, hipMemcpyHostToDevice, c.stream));
-    launch_pointwise(c, dr, da, db, count, c.stream);
-    LSR_HIP(hipMemcpyAsync(result, dr, count * 8, hipMemcpyDeviceToHost, c.stream));
-    LSR_HIP(hipStreamSynchronize(c.stream));
+    LSR_HIP(hipMemcpyAsync(da, a, count * 8, hipMemcpyHostToDevice, work_stream(c)));
+    LSR_HIP(hipMemcpyAsync(db, b, count * 8, hipMemcpyHostToDevice, work_stream(c)));
+    launch_pointwise(c, dr, da, db, count, work_stream(c));
+    LSR_HIP(hipMemcpyAsync(result, dr, count * 8, hipMemcpyDeviceToHost, work_stream(c)));
+    LSR_HIP(hipStreamSynchronize(work_stream(c)));
 }
 
 }  // namespace lsr

@@ -465,19 +465,19 @@ static void cyclic_host(const NttContext& c, uint64_t* values, size_t batch, boo
     const size_t n = c.degree;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, (256ull << 20) / (n * 8)));
     DeviceBuffer<uint64_t> x(chunk * n), y(chunk * n);
-    std::lock_guard<std::mutex> lock(c.staging_mutex);   // serialises use of c.stream
+    std::lock_guard<std::mutex> lock(c.staging_mutex);   // serialises use of work_stream(c)
     for (size_t done = 0; done < batch; done += chunk) {
         const size_t now = std::min(chunk, batch - done);
-        LSR_HIP(hipMemcpyAsync(x.ptr, values + done * n, now * n * 8, hipMemcpyHostToDevice, c.stream));
+        LSR_HIP(hipMemcpyAsync(x.ptr, values + done * n, now * n * 8, hipMemcpyHostToDevice, work_stream(c)));
         if (inverse) {
-            launch_bit_reverse(y.ptr, x.ptr, c.logn, now, c.stream);
-            launch_ntt(c, y.ptr, now, true, c.stream);
+            launch_bit_reverse(y.ptr, x.ptr, c.logn, now, work_stream(c));
+            launch_ntt(c, y.ptr, now, true, work_stream(c));
         } else {
-            launch_ntt(c, x.ptr, now, false, c.stream);
-            launch_bit_reverse(y.ptr, x.ptr, c.logn, now, c.stream);
+            launch_ntt(c, x.ptr, now, false, work_stream(c));
+            launch_bit_reverse(y.ptr, x.ptr, c.logn, now, work_stream(c));
         }
-        LSR_HIP(hipMemcpyAsync(values + done * n, y.ptr, now * n * 8, hipMemcpyDeviceToHost, c.stream));
-        LSR_HIP(hipStreamSynchronize(c.stream));
+        LSR_HIP(hipMemcpyAsync(values + done * n, y.ptr, now * n * 8, hipMemcpyDeviceToHost, work_stream(c)));
+        LSR_HIP(hipStreamSynchronize(work_stream(c)));
     }
 }
 

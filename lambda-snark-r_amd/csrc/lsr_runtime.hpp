@@ -94,7 +94,10 @@ struct NttContext {
     // staging for the single-polynomial host-pointer entry points
     mutable std::mutex staging_mutex;
     mutable lsr::DeviceBuffer<uint64_t> staging;   // 3 n words
-    hipStream_t stream = nullptr;
+    // the context's own stream for the host-pointer entry points — created on first use (lsr::work_stream): device-API callers
+    // bring their stream, and every stream a process opens competes for the runtime's few hardware queues
+    mutable std::mutex stream_mutex;
+    mutable hipStream_t stream = nullptr;
 };
 
 namespace lsr {
@@ -103,6 +106,7 @@ NttContext* create_ntt_context(uint64_t q, uint32_t n, int device);
 // cyclic transform over F_q with the given primitive n-th root (0 = the reference's root for NTT_MODULUS)
 NttContext* create_cyclic_ntt_context(uint64_t q, uint32_t n, uint64_t omega, int device);
 void destroy_ntt_context(NttContext* ctx);
+hipStream_t work_stream(const NttContext& ctx);
 // asynchronous launches on `stream`, data resident on ctx->device
 // add_on_inverse (optional): canonical residues [batch][n] added to the outputs of an inverse transform in its final
 // store (the commitment's fused blinding add)
