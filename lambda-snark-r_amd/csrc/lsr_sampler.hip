@@ -22,11 +22,16 @@ __global__ void __launch_bounds__(kSamplerThreads) gaussian_kernel(GaussianJob j
     const uint64_t blocks_per_object = (job.samples + kSamplesPerBlock - 1) / kSamplesPerBlock;
     const uint64_t gid = (uint64_t)blockIdx.x * kSamplerThreads + threadIdx.x;
     if (gid >= blocks_per_object * job.objects) return;
-    const uint64_t object = gid / blocks_per_object;
-    const uint64_t block = gid - object * blocks_per_object;
-    const uint64_t index = job.index_base + object % job.components;
+    // lane -> (object, block): ring degrees are powers of two, so the usual case is a shift; a software 64-bit division per
+    // lane (three of them) was a tenth of this kernel
+    uint64_t object, block;
+    if (job.objects == 1) { object = 0; block = gid; }
+    else if ((blocks_per_object & (blocks_per_object - 1)) == 0) { object = gid >> (63 - __clzll((long long)blocks_per_object)); block = gid & (blocks_per_object - 1); }
+    else { object = gid / blocks_per_object; block = gid - object * blocks_per_object; }
+    const uint32_t group = (uint32_t)object / job.components;            // objects < 2^32 (launch_gaussian)
+    const uint64_t index = job.index_base + ((uint32_t)object - group * job.components);
     uint64_t w[8];
-    stream_block(job.keys + 4 * (object / job.components), job.domain, index, (uint32_t)block, w);
+    stream_block(job.keys + 4 * (size_t)group, job.domain, index, (uint32_t)block, w);
     uint64_t* dst = job.out + object * job.samples + block * kSamplesPerBlock;
     const uint64_t left = job.samples - block * kSamplesPerBlock;
     uint64_t u[8];
@@ -76,6 +81,7 @@ __global__ void __launch_bounds__(kSamplerThreads) splitmix_kernel(uint64_t* __r
 void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream) {
     const uint64_t lanes = ((job.samples + kSamplesPerBlock - 1) / kSamplesPerBlock) * job.objects;
     if (!lanes) return;
+    if (job.objects > 0xFFFFFFFFull || job.components == 0) throw std::runtime_error("gaussian job: objects must fit 32 bits, components >= 1");
     const unsigned grid = static_cast<unsigned>((lanes + kSamplerThreads - 1) / kSamplerThreads);
     hipLaunchKernelGGL(gaussian_kernel, dim3(grid), dim3(kSamplerThreads), entries * sizeof(uint64_t), stream, job, d_cdf, entries);
     LSR_HIP(hipGetLastError());

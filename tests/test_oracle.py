@@ -142,6 +142,23 @@ def _moments_ok(v, sigma):
     return abs(v.mean()) < 0.5 and abs(v.std(ddof=1) - sigma) < 0.8 and pos > v.size / 4 and neg > v.size / 4 and abs(pos - neg) < v.size / 5
 
 
+def test_seeded_sampler_spends_one_stream_word_per_sample(oracle):
+    """The library's seeded sampler (lsr_sampler.hpp): sample i = stream word i of its object; low bit = sign
+    (ignored for magnitude 0, utils.cpp:114-120), upper 63 bits against the table at 63-bit precision — first k with
+    cdf[k] >> 1 >= word >> 1 (the reference's first-k-with-cdf>=u scan, utils.cpp:101-108).  Restated in Python integers."""
+    for sigma, seed, domain, index in ((3.19, 42, 16, 3), (1.0, 7, 5, 0), (8.0, 0x1234, 4, 2)):
+        cdf = [int(x) >> 1 for x in oracle.gaussian_cdf(sigma)]
+        words = [int(x) for x in oracle.stream_words(seed, domain, index, 0, 300)]
+        want = []
+        for w in words:
+            k = next(i for i, c in enumerate(cdf) if c >= (w >> 1))
+            want.append(-k if (w & 1) and k else k)
+        assert [int(x) for x in oracle.sample_gaussian_seeded(300, sigma, seed, domain, index)] == want
+    # the two halves of the distribution are used: magnitudes reach past sigma on both sides
+    v = oracle.sample_gaussian_seeded(4096, 3.19, 99, 16, 0)
+    assert v.min() < -6 and v.max() > 6
+
+
 def test_sampler_moments(oracle):
     rc, v = oracle.sample_gaussian(4096, 3.2)
     assert rc == 0 and _moments_ok(v, 3.2)
