@@ -36,13 +36,18 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
            "forward_bytes_per_transform": sum(moved(ntt[k]) for k in fwd) / 512, "inverse_bytes_per_transform": sum(moved(ntt[k]) for k in inv) / 512,
            "algorithmic_bytes_per_transform": 1048576, "kernels_forward": fwd, "kernels_inverse": inv}, open(f"{out}/roofline_inputs.json", "w"), indent=1)
 com = per_kernel("pmc_commit")
-pipeline = [k for k in com if "mlwe_mid" in k or "strided_round" in k]
+# commit_bench.py runs the e1-given pipeline (forward round, middle stage, inverse round + e1) and the e1-sampled one (the inverse
+# round is then ntt_strided_round_sampled); the forward round and the middle stage are the same kernels in both
+pipeline = [k for k in com if "mlwe_mid" in k or ("strided_round" in k and "sampled" not in k)]
 per_commit = sum(moved(com[k]) for k in pipeline) / 64          # 64 witness vectors per dispatch (128 MiB chunks at rank 4)
+sampled = [k for k in com if "mlwe_mid" in k or ("strided_round" in k and ("sampled" in k or "false, false, true" in k))]
+per_commit_sampled = sum(moved(com[k]) for k in sampled) / 64
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on J=256 tools/commit_bench.py, rank 4, n=2^16, 64 witness vectors per dispatch; FETCH_SIZE doubled",
            "bytes_per_commit": per_commit, "algorithmic_bytes_per_commit": 6291456,
+           "bytes_per_commit_e1_sampled_in_pass": per_commit_sampled, "algorithmic_bytes_per_commit_e1_sampled": 4194304,
            "kernel": "ntt_strided_round<F64,4> fwd (r -> workspace) + mlwe_mid_fused8<4> + ntt_strided_round<F64,4> inv (+ e1), per 64-vector chunk",
            "per_kernel": {k: com[k] for k in com}}, open(f"{out}/pmc_commit_traffic.json", "w"), indent=1)
-print("forward bytes/transform", sum(moved(ntt[k]) for k in fwd) / 512, "commit bytes", per_commit, per_commit / 2**20, "MiB")
+print("forward bytes/transform", sum(moved(ntt[k]) for k in fwd) / 512, "commit bytes", per_commit, per_commit / 2**20, "MiB", "sampled", per_commit_sampled / 2**20, "MiB")
 PY
 python3 -c "
 import json; d=json.load(open('$out/bench.json')); e=d['extra']
