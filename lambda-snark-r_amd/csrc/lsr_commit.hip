@@ -700,8 +700,11 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
     if (c.ws_mid.count < slot_words * streams) c.ws_mid.allocate(slot_words * streams);
     const bool sample = !d_e1 && d_keys;
     const bool split88 = c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) == 88;
-    const bool slots_needed = sample && (split88 || !env_int("LAMBDA_SNARK_COMMIT_SAMPLE_IN_PASS", 1, 0, 1));
-    if (slots_needed && c.ws_e1_slots.count < slot_words * streams) c.ws_e1_slots.allocate(slot_words * streams);
+    const bool in_pass = sample && !split88 && env_int("LAMBDA_SNARK_COMMIT_SAMPLE_IN_PASS", 1, 0, 1);
+    const bool split_sampling = in_pass && c.cdf_entries <= 127 && env_int("LAMBDA_SNARK_COMMIT_SAMPLE_SPLIT", 1, 0, 1);
+    const size_t side_words = slot_words / 16;                    // int8 samples of half the rows: 1/16 of the chunk's words
+    const size_t e1_words = !sample ? 0 : (in_pass ? (split_sampling ? side_words : 0) : slot_words);
+    if (e1_words && c.ws_e1_slots.count < e1_words * streams) c.ws_e1_slots.allocate(e1_words * streams);
     if (streams > 1) LSR_HIP(hipEventRecord(c.ev_fork, s));
     for (int i = 1; i < streams; ++i) LSR_HIP(hipStreamWaitEvent(lane(i), c.ev_fork, 0));
     size_t index = 0;
@@ -734,14 +737,19 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
             LSR_HIP(hipGetLastError());
             continue;
         }
-        launch_top_round_forward(*c.ntt, ws, d_r + first * vec_words, now * k, st);
+        // split of the in-pass sampling (LAMBDA_SNARK_COMMIT_SAMPLE_SPLIT, default 1): the forward round samples the first half of the
+        // rows into a side slot as int8 (vec_words / 16 words per vector), the inverse round reads it and samples the other half
+        BlindSampler bs{d_keys + 4 * first, c.cdf.ptr, c.cdf_entries, k, kDomE1, nullptr};
+        if (sample_in_pass && split_sampling) bs.side = c.ws_e1_slots.ptr + (index % streams) * side_words;
+        if (bs.side) launch_top_round_forward_sampling(*c.ntt, ws, d_r + first * vec_words, now * k, st, bs);
+        else launch_top_round_forward(*c.ntt, ws, d_r + first * vec_words, now * k, st);
         switch (k) {
             case 1: launch_mid<1>(c, ws, out, now, st); break;
             case 2: launch_mid<2>(c, ws, out, now, st); break;
             case 3: launch_mid<3>(c, ws, out, now, st); break;
             default: launch_mid<4>(c, ws, out, now, st); break;
         }
-        if (sample_in_pass) launch_top_round_inverse_sampled(*c.ntt, out, now * k, st, BlindSampler{d_keys + 4 * first, c.cdf.ptr, c.cdf_entries, k, kDomE1});
+        if (sample_in_pass) launch_top_round_inverse_sampled(*c.ntt, out, now * k, st, bs);
         else launch_top_round_inverse(*c.ntt, out, now * k, st, blind);
     }
     for (int i = 1; i < streams; ++i) {

@@ -378,14 +378,30 @@ void launch_top_round_inverse_sampled(const NttContext& c, uint64_t* data, size_
     const int r_top = std::max(c.logn - kTileLog, 4), lo = c.logn - r_top;
     const size_t total = polys << c.logn;
     const unsigned grid = static_cast<unsigned>(((total >> r_top) + kThreads - 1) / kThreads);
-    const unsigned lds = (((bs.entries + 1u) & ~1u) * 8u) + (kThreads << r_top) * 4u;       // table + [2^r][256] int32
+    const bool half = bs.side != nullptr;                                 // rows [0, 2^r / 2) were sampled by the forward round
+    const unsigned lds = (((bs.entries + 1u) & ~1u) * 8u) + ((kThreads << r_top) >> (half ? 1 : 0)) * 4u;   // table + int32 tile
     const auto cs = Flavour<ArithF64>::consts(c);
-    if (r_top == 4)
-        hipLaunchKernelGGL((ntt_strided_round_sampled<ArithF64, 4, true>), dim3(grid), dim3(kThreads), lds, s, data, total, lo, c.mod, Flavour<ArithF64>::inv(c), cs, bs);
-    else if (r_top == 5)
-        hipLaunchKernelGGL((ntt_strided_round_sampled<ArithF64, 5, true>), dim3(grid), dim3(kThreads), lds, s, data, total, lo, c.mod, Flavour<ArithF64>::inv(c), cs, bs);
-    else
-        throw std::runtime_error("top-round launch: 4 or 5 top bits only");
+    const auto* tw = Flavour<ArithF64>::inv(c);
+    if (r_top == 4 && !half) hipLaunchKernelGGL((ntt_strided_round_sampled<ArithF64, 4, true, false>), dim3(grid), dim3(kThreads), lds, s, data, total, lo, c.mod, tw, cs, bs);
+    else if (r_top == 4) hipLaunchKernelGGL((ntt_strided_round_sampled<ArithF64, 4, true, true>), dim3(grid), dim3(kThreads), lds, s, data, total, lo, c.mod, tw, cs, bs);
+    else if (r_top == 5 && !half) hipLaunchKernelGGL((ntt_strided_round_sampled<ArithF64, 5, true, false>), dim3(grid), dim3(kThreads), lds, s, data, total, lo, c.mod, tw, cs, bs);
+    else if (r_top == 5) hipLaunchKernelGGL((ntt_strided_round_sampled<ArithF64, 5, true, true>), dim3(grid), dim3(kThreads), lds, s, data, total, lo, c.mod, tw, cs, bs);
+    else throw std::runtime_error("top-round launch: 4 or 5 top bits only");
+    LSR_HIP(hipGetLastError());
+}
+
+void launch_top_round_forward_sampling(const NttContext& c, uint64_t* dst, const uint64_t* src, size_t polys, hipStream_t s, const BlindSampler& bs) {
+    if (!c.use_f64 || c.logn <= kTileLog) throw std::runtime_error("top-round launch: FP64 flavour, n > 4096 only");
+    if (!bs.side || bs.entries > 127) throw std::runtime_error("forward sampling: side buffer and a table of <= 127 entries needed");
+    const int r_top = std::max(c.logn - kTileLog, 4), lo = c.logn - r_top;
+    const size_t total = polys << c.logn;
+    const unsigned grid = static_cast<unsigned>(((total >> r_top) + kThreads - 1) / kThreads);
+    const unsigned lds = (((bs.entries + 1u) & ~1u) * 8u) + ((kThreads << r_top) >> 1);                      // table + int8 tile
+    const auto cs = Flavour<ArithF64>::consts(c);
+    const auto* tw = Flavour<ArithF64>::fwd(c);
+    if (r_top == 4) hipLaunchKernelGGL((ntt_strided_round_sampling<ArithF64, 4>), dim3(grid), dim3(kThreads), lds, s, dst, total, lo, c.mod, tw, cs, src, bs);
+    else if (r_top == 5) hipLaunchKernelGGL((ntt_strided_round_sampling<ArithF64, 5>), dim3(grid), dim3(kThreads), lds, s, dst, total, lo, c.mod, tw, cs, src, bs);
+    else throw std::runtime_error("top-round launch: 4 or 5 top bits only");
     LSR_HIP(hipGetLastError());
 }
 

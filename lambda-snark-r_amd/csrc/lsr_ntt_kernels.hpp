@@ -327,17 +327,24 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
 // 2^(R-1-j) + u for every lane of every polynomial: compile-time indices, scalar loads, no VGPRs for twiddles.
 // ADD: canonical residues `add` are added to the outputs in the final store (inverse, last pass only).
 // Forward rounds (ADD is then false): a non-null `add` is the array to READ the operands from (out-of-place first pass).
-// SAMPLE (with ADD): the blinding residues are not read from `add` but SAMPLED here, in the pass that consumes them — the CDT
-// Gaussian of lsr_sampler.hpp, object = polynomial (key bs.keys[4 (poly / components)], stream index poly % components).  A
-// workgroup owns 256 columns x 2^R rows of one polynomial = 2^R * 32 ChaCha blocks of 8 consecutive coefficients, 2^R / 8 blocks
-// per lane; the samples change hands through LDS ([row][column] int32).  The operand loads are issued first and are in flight
-// under the cipher work, so the integer-bound sampler and the memory-bound round share one pass (and e1 never exists in memory).
-template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT, bool ADD, bool SAMPLE>
+// SM (sampling mode; 1 and 2 with ADD): the blinding residues are not read from `add` but SAMPLED in the passes around the middle
+// stage — the CDT Gaussian of lsr_sampler.hpp, object = polynomial (key bs.keys[4 (poly / components)], stream index
+// poly % components).  A workgroup owns 256 columns x 2^R rows of one polynomial = 2^R * 32 ChaCha blocks of 8 consecutive
+// coefficients; the samples change hands through LDS.  The operand loads are issued first and are in flight under the cipher
+// work, so the integer-bound sampler and the memory-bound round share a pass, and e1 never exists in memory as residues.
+//   SM = 1: the last inverse round samples all 2^R rows itself (2^R / 8 blocks per lane);
+//   SM = 3 + SM = 2: the FORWARD round of the same chunk (its VALU is as idle as the inverse round's) samples rows [0, 2^R / 2) and
+//            leaves them in bs.side as int8, one byte per row packed per column ([polynomial][column][2^R / 16] words: 1/16 of a
+//            polynomial pass); the inverse round reads that and samples rows [2^R / 2, 2^R) — the cipher work split over two passes.
+//            Needs table entries <= 127 (magnitudes fit a byte).
+template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT, bool ADD, int SM>
 __device__ __forceinline__ void strided_round_body(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
                                                    const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
                                                    const uint64_t* __restrict__ add, const BlindSampler& bs) {
     static_assert(!ADD || (INVERSE && !RAW_OUT), "the fused add belongs to the last inverse pass");
-    static_assert(!SAMPLE || (ADD && R >= 3), "sampling replaces the read of the blinding residues; 2^R / 8 blocks per lane");
+    static_assert(SM == 0 || R >= 4, "2^R / 16 blocks per lane and half");
+    static_assert((SM != 1 && SM != 2) || ADD, "sampling replaces the read of the blinding residues");
+    static_assert(SM != 3 || (!INVERSE && !ADD), "the forward round only prepares samples");
     using elem = typename A::elem;
     constexpr int N = 1 << R;
     const size_t group = (size_t)blockIdx.x * kThreads + threadIdx.x;
@@ -362,35 +369,74 @@ __device__ __forceinline__ void strided_round_body(uint64_t* __restrict__ data, 
             v[k] = RAW_IN ? elem_from_bits<A>(raw) : A::load(raw, p);
         }
     }
-    if constexpr (SAMPLE) {
+    if constexpr (SM != 0) {
         extern __shared__ uint64_t lds_words[];
         uint64_t* const cdf63 = lds_words;
-        int32_t* const tile = reinterpret_cast<int32_t*>(lds_words + ((bs.entries + 1u) & ~1u));
+        uint64_t* const tile_words = lds_words + ((bs.entries + 1u) & ~1u);
         for (uint32_t i = threadIdx.x; i < bs.entries; i += kThreads) cdf63[i] = bs.cdf[i] >> 1;
         __syncthreads();
         const size_t g0 = (size_t)blockIdx.x * kThreads;               // workgroup-uniform: polynomial and first column
         const uint32_t poly = (uint32_t)(g0 >> lo), low0 = (uint32_t)(g0 & (((size_t)1 << lo) - 1));
         const uint64_t* const key = bs.keys + 4 * (size_t)(poly / bs.components);
+        constexpr int kRows = SM == 1 ? N : N / 2;                      // rows sampled by this pass
+        constexpr int kRow0 = SM == 2 ? N / 2 : 0;                      // first of them
+        constexpr int kSideWords = N / 16;                              // packed words per column in bs.side
 #pragma unroll 1
-        for (int h = 0; h < N / 8; ++h) {
+        for (int h = 0; h < kRows / 8; ++h) {
             const uint32_t b = (uint32_t)h * kThreads + threadIdx.x, row = b >> 5, cb = b & 31u;
             uint64_t w[8], u[8];
-            stream_block(key, bs.domain, poly % bs.components, (((row << lo) + low0) >> 3) + cb, w);
+            stream_block(key, bs.domain, poly % bs.components, ((((kRow0 + row) << lo) + low0) >> 3) + cb, w);
 #pragma unroll
             for (int i = 0; i < 8; ++i) u[i] = w[i] >> 1;
             uint32_t magnitude[8];
             cdt_scan<8>(cdf63, bs.entries, u, magnitude);
+            if constexpr (SM == 3) {                                    // int8 tile [row][256 columns]: eight samples = one LDS word
+                uint64_t packed = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int32_t m = (int32_t)magnitude[i], sign = (int32_t)(w[i] & 1ull);
-                tile[row * kThreads + cb * 8 + i] = sign ? -m : m;
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t m = magnitude[i], sign = (uint32_t)(w[i] & 1ull);
+                    packed |= (uint64_t)((sign ? 0u - m : m) & 0xFFu) << (8 * i);
+                }
+                tile_words[row * (kThreads / 8) + cb] = packed;
+            } else {                                                    // int32 tile [row][256 columns]
+                int32_t* const tile = reinterpret_cast<int32_t*>(tile_words);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int32_t m = (int32_t)magnitude[i], sign = (int32_t)(w[i] & 1ull);
+                    tile[row * kThreads + cb * 8 + i] = sign ? -m : m;
+                }
             }
         }
         __syncthreads();
+        if constexpr (SM == 3) {                                        // column j: one byte per row, packed row-major into words
+            const uint8_t* const bytes = reinterpret_cast<const uint8_t*>(tile_words);
+            uint64_t* const dst = bs.side + ((size_t)poly << lo) * kSideWords + (size_t)(low0 + threadIdx.x) * kSideWords;
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const int32_t e = tile[k * kThreads + threadIdx.x];
-            extra[k] = e < 0 ? p.q - (uint64_t)(-e) : (uint64_t)e;
+            for (int wd = 0; wd < kSideWords; ++wd) {
+                uint64_t packed = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) packed |= (uint64_t)bytes[(wd * 8 + i) * kThreads + threadIdx.x] << (8 * i);
+                dst[wd] = packed;
+            }
+        } else {
+            const int32_t* const tile = reinterpret_cast<const int32_t*>(tile_words);
+            if constexpr (SM == 2) {
+                const uint64_t* const src = bs.side + ((size_t)poly << lo) * kSideWords + (size_t)(low0 + threadIdx.x) * kSideWords;
+#pragma unroll
+                for (int wd = 0; wd < kSideWords; ++wd) {
+                    const uint64_t packed = __builtin_nontemporal_load(src + wd);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int32_t e = (int32_t)(int8_t)(packed >> (8 * i));
+                        extra[wd * 8 + i] = e < 0 ? p.q - (uint64_t)(-e) : (uint64_t)e;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kRows; ++k) {
+                const int32_t e = tile[k * kThreads + threadIdx.x];
+                extra[kRow0 + k] = e < 0 ? p.q - (uint64_t)(-e) : (uint64_t)e;
+            }
         }
     } else if constexpr (ADD) {   // the blinding residues travel with the operands, not behind the arithmetic
 #pragma unroll
@@ -450,14 +496,23 @@ template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT, bool ADD>
 __global__ void __launch_bounds__(kThreads) ntt_strided_round(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
                                                                 const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
                                                                 const uint64_t* __restrict__ add) {
-    strided_round_body<A, R, INVERSE, RAW_IN, RAW_OUT, ADD, false>(data, total, lo, p, tw, cs, add, BlindSampler{});
+    strided_round_body<A, R, INVERSE, RAW_IN, RAW_OUT, ADD, 0>(data, total, lo, p, tw, cs, add, BlindSampler{});
 }
 
-// last pass of an inverse transform with the blinding residues sampled in place (dynamic LDS: table + 2^R x 256 int32)
-template <class A, int R, bool RAW_IN>
+// last pass of an inverse transform with the blinding residues sampled in place (dynamic LDS: table + sample tile); HALF: the first
+// half of the rows comes from bs.side, written by ntt_strided_round_sampling of the same chunk
+template <class A, int R, bool RAW_IN, bool HALF>
 __global__ void __launch_bounds__(kThreads) ntt_strided_round_sampled(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
                                                                         const typename A::twid* __restrict__ tw, RoundConsts<A> cs, BlindSampler bs) {
-    strided_round_body<A, R, true, RAW_IN, false, true, true>(data, total, lo, p, tw, cs, nullptr, bs);
+    strided_round_body<A, R, true, RAW_IN, false, true, HALF ? 2 : 1>(data, total, lo, p, tw, cs, nullptr, bs);
+}
+// first (out-of-place, raw-out) round of a forward transform that also samples the first half of the rows of the blinding
+// polynomial of the same index into bs.side
+template <class A, int R>
+__global__ void __launch_bounds__(kThreads) ntt_strided_round_sampling(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
+                                                                         const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
+                                                                         const uint64_t* __restrict__ src, BlindSampler bs) {
+    strided_round_body<A, R, false, false, true, false, 3>(data, total, lo, p, tw, cs, src, bs);
 }
 
 // ---- pointwise product (ntt.cpp:106-119) ------------------------------------------------------------

@@ -123,6 +123,10 @@ void launch_top_round_inverse(const NttContext& ctx, uint64_t* d_data, size_t po
 // the same round with the added residues sampled in the pass (CDT Gaussian per polynomial, lsr_sampler.hpp) instead of read
 struct BlindSampler;
 void launch_top_round_inverse_sampled(const NttContext& ctx, uint64_t* d_data, size_t polys, hipStream_t stream, const BlindSampler& sampler);
+// split sampling (sampler.side != NULL in both calls): the forward round of a chunk also samples the first half of the rows of the
+// residues its inverse round will add, into sampler.side ([polys][n / 2^r][2^r / 16] words, int8 per sample)
+void launch_top_round_forward_sampling(const NttContext& ctx, uint64_t* d_dst, const uint64_t* d_src, size_t polys, hipStream_t stream,
+                                       const BlindSampler& sampler);
 void launch_pointwise(const NttContext& ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* d_b, size_t count,
                       hipStream_t stream);
 // out[b][i] = in[b][bitrev_logn(i)] (out != in)

@@ -94,6 +94,7 @@ struct BlindSampler {
     const uint64_t* keys = nullptr;     // [objects / components][4]
     const uint64_t* cdf = nullptr;      // CDT table (64-bit thresholds)
     uint32_t entries = 0, components = 1, domain = 0;
+    uint64_t* side = nullptr;           // split sampling: int8 samples of the first half of the rows, [polynomial][column][2^R / 16] words
 };
 
 void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream);

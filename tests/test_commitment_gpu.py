@@ -376,14 +376,14 @@ def test_fused_pipeline_every_rank_and_degree(pkg, oracle, n, k, batch):
 @pytest.mark.parametrize("env", [{"LAMBDA_SNARK_COMMIT_SPLIT": "88"}, {"LAMBDA_SNARK_COMMIT_SPLIT": "88", "LAMBDA_SNARK_COMMIT_MID_WAVES": "4"},
                                  {"LAMBDA_SNARK_COMMIT_SPLIT": "88", "LAMBDA_SNARK_COMMIT_MID_WAVES": "4", "LAMBDA_SNARK_COMMIT_TWO_LANE": "1"},
                                  {"LAMBDA_SNARK_COMMIT_FUSED": "0"},
-                                 {"LAMBDA_SNARK_COMMIT_SAMPLE_IN_PASS": "0"},
+                                 {"LAMBDA_SNARK_COMMIT_SAMPLE_IN_PASS": "0"}, {"LAMBDA_SNARK_COMMIT_SAMPLE_SPLIT": "0"},
                                  {"LAMBDA_SNARK_COMMIT_TWO_LANE": "1"},
                                  {"LAMBDA_SNARK_COMMIT_TWO_LANE": "1", "LAMBDA_SNARK_COMMIT_OUTER_CUS": "12"},
                                  {"LAMBDA_SNARK_COMMIT_STREAMS": "1"}, {"LAMBDA_SNARK_COMMIT_STREAMS": "3", "LAMBDA_SNARK_COMMIT_STREAM_MODE": "1"}])
 def test_alternative_commit_pipelines_agree(pkg, oracle, env, monkeypatch):
     """The selectable pipelines of the n = 2^16 matrix–vector product — the 8 + 8 split with the barrier-free middle stage
     (8- and 4-wave workgroups), the two-lane schedule on either split (plain and CU-masked lanes), the unfused round-1 kernels,
-    blinding sampled into a slot instead of inside the last inverse round, one and three chunk lanes — give the oracle's words."""
+    blinding sampled into a slot / wholly inside the last inverse round instead of split over the two strided rounds, one and three chunk lanes — give the oracle's words."""
     import torch
     for key, value in env.items():
         monkeypatch.setenv(key, value)
