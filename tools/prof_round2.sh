@@ -38,9 +38,9 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
 com = per_kernel("pmc_commit")
 # commit_bench.py runs the e1-given pipeline (forward round, middle stage, inverse round + e1) and the e1-sampled one (the inverse
 # round is then ntt_strided_round_sampled); the forward round and the middle stage are the same kernels in both
-pipeline = [k for k in com if "mlwe_mid" in k or ("strided_round" in k and "sampled" not in k)]
+pipeline = [k for k in com if "mlwe_mid" in k or ("ntt_strided_round<" in k)]
 per_commit = sum(moved(com[k]) for k in pipeline) / 64          # 64 witness vectors per dispatch (128 MiB chunks at rank 4)
-sampled = [k for k in com if "mlwe_mid" in k or ("strided_round" in k and ("sampled" in k or "false, false, true" in k))]
+sampled = [k for k in com if "mlwe_mid" in k or "ntt_strided_round_sampl" in k]     # ..._sampling (forward) + ..._sampled (inverse)
 per_commit_sampled = sum(moved(com[k]) for k in sampled) / 64
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on J=256 tools/commit_bench.py, rank 4, n=2^16, 64 witness vectors per dispatch; FETCH_SIZE doubled",
            "bytes_per_commit": per_commit, "algorithmic_bytes_per_commit": 6291456,
