@@ -83,6 +83,38 @@ while time.time() < deadline:
             w, ln = orc.quotient(a[i], b[i], c[i])
             if lens[i] != ln or (ln and not np.array_equal(quot[i], w)): report("quotient", m=m, i=i, ln=ln, got=int(lens[i]))
         plan.close()
+    elif which == 9:         # fused matrix-vector commitment pipeline at the two-pass degrees (given and device-sampled blinding)
+        import torch
+        logn = 16 if rng.integers(0, 4) else 17
+        n = 1 << logn; k = int(rng.integers(1, 5))
+        q = prime_for(n, 44)
+        batch = int(rng.integers(1, 12)) if rng.integers(0, 2) else int(rng.integers(60, 70)) if logn == 16 else int(rng.integers(28, 40))
+        lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=int(rng.integers(1, 2**62)))
+        a_hat = lctx.public_matrix()
+        r = fill(q, (batch, k, n))
+        seeds = rng.integers(1, 2**62, size=batch, dtype=np.uint64)
+        st = torch.cuda.current_stream().cuda_stream
+        d_r = torch.from_numpy(r.view(np.int64)).cuda(); d_u = torch.empty_like(d_r)
+        sampled = bool(rng.integers(0, 2))
+        picks = sorted({0, batch - 1, int(rng.integers(0, batch))})
+        def blinding(j):
+            e = np.stack([orc.sample_gaussian_seeded(n, 3.19, int(seeds[j]), 5, i) for i in range(k)])
+            return np.where(e < 0, e + q, e).astype(np.uint64)
+        if sampled:
+            rc = lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), None, d_u.data_ptr(), batch, seeds.ctypes.data, st)
+            e1 = {j: blinding(j) for j in picks}
+        else:
+            e_all = fill(q, (batch, k, n))
+            d_e = torch.from_numpy(e_all.view(np.int64)).cuda()
+            rc = lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), d_e.data_ptr(), d_u.data_ptr(), batch, None, st)
+            e1 = {j: e_all[j] for j in picks}
+        torch.cuda.synchronize()
+        if rc != 0: report("fused matvec rc", n=n, k=k, batch=batch, rc=rc)
+        for j in picks:
+            if not np.array_equal(d_u[j].cpu().numpy().view(np.uint64), orc.mlwe_matvec(q, n, k, a_hat, r[j], e1[j])):
+                report("fused matvec", n=n, k=k, batch=batch, j=j, sampled=sampled)
+        if not np.array_equal(d_r.cpu().numpy().view(np.uint64), r): report("fused matvec clobbered r", n=n, k=k)
+        lctx.close(); del d_r, d_u
     elif which == 10:        # R1CS-level prover: random sparse systems with a constructed satisfying witness
         m = 1 << int(rng.integers(0, 8)); free = int(rng.integers(1, 12)); nv = free + m
         a, b, c = [], [], []
