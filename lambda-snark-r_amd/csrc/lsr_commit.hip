@@ -594,7 +594,7 @@ static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const
         uint64_t* const ws = c.ws_mid.ptr + (ci % kSlots) * slot_words;
         mark_begin('F', ci, outer);
         if (split88)
-            hipLaunchKernelGGL(cols8_forward<true>, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, ws, d_r + first * vec_words,
+            hipLaunchKernelGGL((cols8_forward<true, 16>), dim3(static_cast<unsigned>(now * k * 16)), dim3(c8_threads<16>()), 0, outer, ws, d_r + first * vec_words,
                                (uint32_t)(now * k), c.ntt->mod, c.ntt->fwd_f64.ptr);
         else
             launch_top_round_forward(*c.ntt, ws, d_r + first * vec_words, now * k, outer);
@@ -634,7 +634,7 @@ static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const
         LSR_HIP(hipStreamWaitEvent(outer, c.ev_middle[ci % LweContext::kRing], 0));
         mark_begin('I', ci, outer);
         if (split88)
-            hipLaunchKernelGGL(cols8_inverse<true>, dim3(static_cast<unsigned>(now * k * 16)), dim3(kC8Threads), 0, outer, d_u + first * vec_words,
+            hipLaunchKernelGGL((cols8_inverse<true, 16>), dim3(static_cast<unsigned>(now * k * 16)), dim3(c8_threads<16>()), 0, outer, d_u + first * vec_words,
                                (uint32_t)(now * k), c.ntt->mod, c.ntt->inv_f64.ptr, cs, blind);
         else
             launch_top_round_inverse(*c.ntt, d_u + first * vec_words, now * k, outer, blind);
@@ -723,17 +723,27 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
         }
         uint64_t* const out = d_u + first * vec_words;
         if (split88) {   // n = 2^16: bits 15..8 | bits 7..0, product, bits 0..7 | bits 8..15 (lsr_commit_fused.hpp, second half)
-            const unsigned cols_grid = static_cast<unsigned>(now * k * 16);
-            hipLaunchKernelGGL(cols8_forward<false>, dim3(cols_grid), dim3(kC8Threads), 0, st, ws, d_r + first * vec_words, (uint32_t)(now * k), c.ntt->mod,
-                               c.ntt->fwd_f64.ptr);
+            // column tile width of the outer passes (LAMBDA_SNARK_COMMIT_COLS = 16 | 32, default 32: 256-byte row segments)
+            const bool wide = env_int("LAMBDA_SNARK_COMMIT_COLS", 32, 16, 32) == 32;
+            const unsigned cols_grid = static_cast<unsigned>(now * k * (wide ? 8 : 16));
+            if (wide)
+                hipLaunchKernelGGL((cols8_forward<false, 32>), dim3(cols_grid), dim3(c8_threads<32>()), 0, st, ws, d_r + first * vec_words, (uint32_t)(now * k),
+                                   c.ntt->mod, c.ntt->fwd_f64.ptr);
+            else
+                hipLaunchKernelGGL((cols8_forward<false, 16>), dim3(cols_grid), dim3(c8_threads<16>()), 0, st, ws, d_r + first * vec_words, (uint32_t)(now * k),
+                                   c.ntt->mod, c.ntt->fwd_f64.ptr);
             switch (k) {
                 case 1: launch_mid8<1>(c, ws, out, now, st); break;
                 case 2: launch_mid8<2>(c, ws, out, now, st); break;
                 case 3: launch_mid8<3>(c, ws, out, now, st); break;
                 default: launch_mid8<4>(c, ws, out, now, st); break;
             }
-            hipLaunchKernelGGL(cols8_inverse<false>, dim3(cols_grid), dim3(kC8Threads), 0, st, out, (uint32_t)(now * k), c.ntt->mod, c.ntt->inv_f64.ptr,
-                               RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64}, blind);
+            if (wide)
+                hipLaunchKernelGGL((cols8_inverse<false, 32>), dim3(cols_grid), dim3(c8_threads<32>()), 0, st, out, (uint32_t)(now * k), c.ntt->mod,
+                                   c.ntt->inv_f64.ptr, RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64}, blind);
+            else
+                hipLaunchKernelGGL((cols8_inverse<false, 16>), dim3(cols_grid), dim3(c8_threads<16>()), 0, st, out, (uint32_t)(now * k), c.ntt->mod,
+                                   c.ntt->inv_f64.ptr, RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64}, blind);
             LSR_HIP(hipGetLastError());
             continue;
         }

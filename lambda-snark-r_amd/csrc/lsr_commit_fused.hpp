@@ -388,22 +388,30 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
 // Index algebra checked on the CPU by tools/experiments/sim_mid8.py.
 // =================================================================================================================================
 
-constexpr int kC8Threads = 256;
-constexpr uint32_t kC8LdsWords = 4096 + 16 * 16;      // tile index i at i + 16 (i >> 8): the second exchange pattern shifts by half a bank row
+// COLS adjacent columns per workgroup (COLS * 16 lanes, 8 * COLS-byte row segments).  16: 256 lanes, 34 KiB of LDS; 32 (default
+// since the late round-2 measurement, profiles/r02_cols_width.txt): 512 lanes, 64 KiB — data movement alone 0.809 ms per 4096
+// polynomials against 0.867 ms with 128-byte segments and 0.779 ms for the strided round (tools/ubench_move2.hip).
+template <int COLS> constexpr int c8_threads() { return COLS * 16; }
+// tile position (row, col): COLS = 16 shifts every block of 16 rows by half a bank row so that the 32 lanes of a ds b64 group
+// (16 columns x 2 row groups) stay on distinct banks in both exchange patterns; with 32 columns a group is one contiguous row segment
+template <int COLS> __host__ __device__ constexpr uint32_t c8_slot(uint32_t row, uint32_t col) {
+    return row * COLS + (COLS == 16 ? 16u * (row >> 4) : 0u) + col;
+}
+template <int COLS> constexpr uint32_t c8_lds_words() { return 256u * COLS + (COLS == 16 ? 256u : 0u); }
 
-// forward: stages of polynomial index bits 15..8 on a tile of 16 adjacent columns (bits 0..3; the column block = bits 4..7 comes
-// from the block index) x 256 rows (bits 8..15)
+// forward: stages of polynomial index bits 15..8 on a tile of COLS adjacent columns x 256 rows (bits 8..15)
 // STREAM: every global access with the nt policy, so that the pass leaves the XCD's L2 to a co-resident middle stage (two-lane schedule)
-template <bool STREAM>
-__global__ void __launch_bounds__(kC8Threads) cols8_forward(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t polys, ModParams p,
-                                                             const double* __restrict__ tw) {
-    __shared__ double lds[kC8LdsWords];
+template <bool STREAM, int COLS>
+__global__ void __launch_bounds__(COLS * 16) cols8_forward(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t polys, ModParams p,
+                                                           const double* __restrict__ tw) {
+    __shared__ double lds[c8_lds_words<COLS>()];
     using A = ArithF64;
+    constexpr uint32_t CB = 256 / COLS;
     const uint32_t t = threadIdx.x;
-    const uint32_t poly = blockIdx.x >> 4, cb = blockIdx.x & 15u;
+    const uint32_t poly = blockIdx.x / CB, cb = blockIdx.x % CB;
     if (poly >= polys) return;
-    const uint32_t col = t & 15u, rr = t >> 4;
-    const size_t base = ((size_t)poly << 16) + (cb << 4) + col;
+    const uint32_t col = t % COLS, rr = t / COLS;
+    const size_t base = ((size_t)poly << 16) + cb * COLS + col;
     double v[16];
     // round 1: registers = bits 12..15, this lane's row bits 8..11 = rr
 #pragma unroll
@@ -422,11 +430,11 @@ __global__ void __launch_bounds__(kC8Threads) cols8_forward(uint64_t* __restrict
         }
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[(k << 8) + 16 * k + (rr << 4) + col] = v[k];
+    for (int k = 0; k < 16; ++k) lds[c8_slot<COLS>(((uint32_t)k << 4) + rr, col)] = v[k];
     __syncthreads();
     // round 2: registers = bits 8..11, this lane's row bits 12..15 = rr
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[(rr << 8) + 16 * rr + (k << 4) + col];
+    for (int k = 0; k < 16; ++k) v[k] = lds[c8_slot<COLS>((rr << 4) + (uint32_t)k, col)];
 #pragma unroll
     for (int j = 3; j >= 0; --j) {                    // polynomial bit b = 8 + j: table[2^(15-b) + (row >> (j + 1))]
         const int half = 1 << j;
@@ -446,16 +454,17 @@ __global__ void __launch_bounds__(kC8Threads) cols8_forward(uint64_t* __restrict
 }
 
 // inverse: stages of bits 8..15 (Gentleman–Sande), n^-1 folded into the last one, + add (canonical residues, optional), canonical out
-template <bool STREAM>
-__global__ void __launch_bounds__(kC8Threads) cols8_inverse(uint64_t* __restrict__ data, uint32_t polys, ModParams p, const double* __restrict__ tw,
-                                                             RoundConsts<ArithF64> cs, const uint64_t* __restrict__ add) {
-    __shared__ double lds[kC8LdsWords];
+template <bool STREAM, int COLS>
+__global__ void __launch_bounds__(COLS * 16) cols8_inverse(uint64_t* __restrict__ data, uint32_t polys, ModParams p, const double* __restrict__ tw,
+                                                           RoundConsts<ArithF64> cs, const uint64_t* __restrict__ add) {
+    __shared__ double lds[c8_lds_words<COLS>()];
     using A = ArithF64;
+    constexpr uint32_t CB = 256 / COLS;
     const uint32_t t = threadIdx.x;
-    const uint32_t poly = blockIdx.x >> 4, cb = blockIdx.x & 15u;
+    const uint32_t poly = blockIdx.x / CB, cb = blockIdx.x % CB;
     if (poly >= polys) return;
-    const uint32_t col = t & 15u, rr = t >> 4;
-    const size_t base = ((size_t)poly << 16) + (cb << 4) + col;
+    const uint32_t col = t % COLS, rr = t / COLS;
+    const size_t base = ((size_t)poly << 16) + cb * COLS + col;
     double v[16];
     // round 1: registers = bits 8..11, lane row bits 12..15 = rr
 #pragma unroll
@@ -471,11 +480,11 @@ __global__ void __launch_bounds__(kC8Threads) cols8_inverse(uint64_t* __restrict
         }
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[(rr << 8) + 16 * rr + (k << 4) + col] = recentre_f64(v[k], p.qd, p.inv_qd);
+    for (int k = 0; k < 16; ++k) lds[c8_slot<COLS>((rr << 4) + (uint32_t)k, col)] = recentre_f64(v[k], p.qd, p.inv_qd);
     __syncthreads();
     // round 2: registers = bits 12..15, lane row bits 8..11 = rr
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[(k << 8) + 16 * k + (rr << 4) + col];
+    for (int k = 0; k < 16; ++k) v[k] = lds[c8_slot<COLS>(((uint32_t)k << 4) + rr, col)];
     uint64_t blind[16];
     if (add != nullptr) {
 #pragma unroll

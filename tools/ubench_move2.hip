@@ -66,6 +66,38 @@ __global__ void __launch_bounds__(256) pass1_cols(uint64_t* __restrict__ d, size
     for (int k = 0; k < 16; ++k) st<1, NTS>(d + base + ((size_t)k << 12), v[k]);
 }
 
+
+// round 2, late: wider column tiles for the 8 + 8 split (COLS adjacent columns x 256 rows, COLS*16 lanes: 8*COLS-byte row
+// segments instead of 128-byte ones) and deeper strided rounds (2^R rows per lane) for 5 + 11 / 6 + 10 splits
+template <int COLS>
+__global__ void __launch_bounds__(COLS * 16) pass1_colsw(uint64_t* __restrict__ d, size_t total) {
+    constexpr int CB = 256 / COLS;                       // column blocks per polynomial
+    const size_t tile = blockIdx.x;
+    const uint32_t col = threadIdx.x % COLS, rr = threadIdx.x / COLS;
+    const size_t base = ((tile / CB) << 16) + ((tile % CB) * COLS) + col + ((size_t)rr << 8);
+    uint64_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = d[base + ((size_t)k << 12)];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = v[k] * 3 + v[(k + 1) & 15];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[base + ((size_t)k << 12)] = v[k];
+}
+template <int R>
+__global__ void __launch_bounds__(256) pass1_deep(uint64_t* __restrict__ d, size_t total) {
+    constexpr int ROWS = 1 << R, SH = 16 - R;
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total / ROWS) return;
+    const size_t idx0 = ((g >> SH) << 16) | (g & ((1u << SH) - 1));
+    uint64_t v[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) v[k] = d[idx0 + ((size_t)k << SH)];
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) v[k] = v[k] * 3 + v[(k + 1) & (ROWS - 1)];
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) d[idx0 + ((size_t)k << SH)] = v[k];
+}
+
 template <class F> static float timed(F&& launch, hipEvent_t a, hipEvent_t b) {
     std::vector<float> ms;
     for (int rep = 0; rep < 7; ++rep) {
@@ -121,5 +153,13 @@ int main() {
         const float t2 = timed([&] { for (size_t c = 0; c < polys; c += chunk_polys) hipLaunchKernelGGL((pass1_cols<false, false>), dim3((unsigned)(chunk / 4096)), dim3(256), pad, 0, data + c * n, chunk); }, a, b);
         printf("LDS pad %6u B (<= %u workgroups per CU): strided rows %.3f ms, 16-column tiles %.3f ms\n", pad, pad ? 163840u / pad : 8u, t1, t2);
     }
+#define RUNW(COLS) timed([&] { for (size_t c = 0; c < polys; c += chunk_polys) hipLaunchKernelGGL((pass1_colsw<COLS>), dim3((unsigned)(chunk / (COLS * 256))), dim3(COLS * 16), 0, 0, data + c * n, chunk); }, a, b)
+#define RUND(R) timed([&] { for (size_t c = 0; c < polys; c += chunk_polys) hipLaunchKernelGGL((pass1_deep<R>), dim3((unsigned)(chunk / (1 << R) / 256)), dim3(256), 0, 0, data + c * n, chunk); }, a, b)
+    printf("pass1 16 cols x 256 rows (256 lanes)   %.3f\n", RUNW(16));
+    printf("pass1 32 cols x 256 rows (512 lanes)   %.3f\n", RUNW(32));
+    printf("pass1 64 cols x 256 rows (1024 lanes)  %.3f\n", RUNW(64));
+    printf("pass1 strided 2^4 rows per lane        %.3f\n", RUND(4));
+    printf("pass1 strided 2^5 rows per lane        %.3f\n", RUND(5));
+    printf("pass1 strided 2^6 rows per lane        %.3f\n", RUND(6));
     return 0;
 }
