@@ -664,6 +664,100 @@ static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const
 #endif
 }
 
+// MIXED schedule of the 4 + 12 pipeline (n = 2^16, blinding residues given or absent; caller holds c.mutex): launch t carries the
+// middle stage of chunk t, the forward strided round of chunk t + 1 and the inverse strided round of chunk t - 1 as roles of one
+// kernel (lsr_commit_fused.hpp, mlwe_mixed), t = -1 .. chunks; two workspace slots alternate.  One stream, no events: the launch
+// boundaries are the dependencies.
+template <int K>
+static void launch_mixed(const LweContext& c, const MixedJob& job, hipStream_t s) {
+    const unsigned grid = (job.units_m + job.units_f + job.units_i) * 8u;
+    if (!grid) return;
+    hipLaunchKernelGGL((mlwe_mixed<K>), dim3(grid), dim3(kF8Threads), 0, s, job, c.a_perm.ptr, c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr,
+                       RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64});
+    LSR_HIP(hipGetLastError());
+}
+
+static void mlwe_matvec_mixed(const LweContext& c, const uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s) {
+    const uint32_t k = c.k;
+    const size_t vec_words = (size_t)k << c.logn;
+    // 64 MiB chunks (32 rank-4 witness vectors): two lanes x two workspace slots x 64 MiB stay inside the 256 MiB Infinity Cache
+    const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_MIX_CHUNK_MIB", 64, 1, 4096);
+    const size_t chunk = std::max<size_t>(1, (chunk_mib << 20) / (vec_words * 8));
+    const long chunks = static_cast<long>((batch + chunk - 1) / chunk);
+    // LAMBDA_SNARK_COMMIT_MIX_LANES (default 2): the chunks alternate between independent pipelines of mixed launches on their own
+    // streams (lane 0 = the caller's stream), so that the drain of one lane's launch is filled by the other's workgroups — all of
+    // one shape, so the dispatcher has no reason to starve either (3.05 -> 2.95 ms per 1024 vectors, profiles/r02_mixed_launch.txt)
+    const int lanes = static_cast<int>(std::min<long>(env_int("LAMBDA_SNARK_COMMIT_MIX_LANES", 2, 1, 3), chunks));
+    const size_t slot_words = std::min(chunk, batch) * vec_words;
+    if (c.ws_mid.count < slot_words * 2 * lanes) c.ws_mid.allocate(slot_words * 2 * lanes);
+    while (c.n_side < lanes - 1) {
+        c.side[c.n_side] = create_side_stream(c.ntt->device, c.n_side);
+        LSR_HIP(hipEventCreateWithFlags(&c.ev_join[c.n_side], hipEventDisableTiming));
+        ++c.n_side;
+    }
+    if (lanes > 1) {
+        if (!c.ev_fork) LSR_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+        LSR_HIP(hipEventRecord(c.ev_fork, s));
+        for (int i = 1; i < lanes; ++i) LSR_HIP(hipStreamWaitEvent(c.side[i - 1], c.ev_fork, 0));
+    }
+    // strided units that follow one middle unit in the block order.  The period (ratio + 1) must stay odd: blocks are dealt to the
+    // XCDs and their CUs round-robin, and with an even period the middle-stage workgroups pile up on a fraction of the CUs
+    // (profiles/r02_mixed_launch.txt: ratio 3 -> 5.5 ms, ratio 2 -> 3.07 ms per 1024 vectors)
+    const int ratio = env_int("LAMBDA_SNARK_COMMIT_MIX_RATIO", 4, 1, 64);
+    const int fgroups = env_int("LAMBDA_SNARK_COMMIT_MIX_FGROUPS", 2, 1, 2);
+    for (long t = -1;; ++t) {
+        bool any = false;
+        for (int lane = 0; lane < lanes; ++lane) {
+            // lane's sequence: chunks lane, lane + lanes, ...; position t of it is chunk lane + t * lanes
+            auto chunk_at = [&](long pos) { return pos < 0 ? -1L : (long)lane + pos * lanes; };
+            auto valid = [&](long pos) { const long ci = chunk_at(pos); return ci >= 0 && ci < chunks; };
+            auto first_of = [&](long pos) { return (size_t)chunk_at(pos) * chunk; };
+            auto count_of = [&](long pos) { return std::min(chunk, batch - first_of(pos)); };
+            uint64_t* const ws = c.ws_mid.ptr + (size_t)lane * 2 * slot_words;
+            MixedJob job{};
+            if (valid(t)) {
+                job.m_ws = ws + (size_t)(t & 1) * slot_words;
+                job.m_out = d_u + first_of(t) * vec_words;
+                job.m_vectors = (uint32_t)count_of(t);
+                job.units_m = job.m_vectors << (c.logn - 12 - 3);
+            }
+            if (valid(t + 1)) {
+                job.f_dst = ws + (size_t)((t + 1) & 1) * slot_words;
+                job.f_src = d_r + first_of(t + 1) * vec_words;
+                job.f_polys = (uint32_t)(count_of(t + 1) * k);
+                // a unit = 8 workgroups of 512 lanes x 16 residues = one polynomial; two polynomials with two groups per lane
+                job.f_groups = (uint32_t)fgroups;
+                job.units_f = (job.f_polys + job.f_groups - 1) / job.f_groups;
+            }
+            if (t >= 1 && valid(t - 1)) {
+                job.i_data = d_u + first_of(t - 1) * vec_words;
+                job.i_add = d_e1 ? d_e1 + first_of(t - 1) * vec_words : nullptr;
+                job.i_polys = (uint32_t)(count_of(t - 1) * k);
+                job.units_i = job.i_polys;
+            }
+            const uint32_t units_s = job.units_f + job.units_i;
+            if (!job.units_m && !units_s) continue;
+            any = true;
+            if (job.units_m && units_s) {
+                job.s_per_m = (uint32_t)ratio;
+                job.periods = std::min(job.units_m, units_s / job.s_per_m);
+            }
+            hipStream_t st = lane == 0 ? s : c.side[lane - 1];
+            switch (k) {
+                case 1: launch_mixed<1>(c, job, st); break;
+                case 2: launch_mixed<2>(c, job, st); break;
+                case 3: launch_mixed<3>(c, job, st); break;
+                default: launch_mixed<4>(c, job, st); break;
+            }
+        }
+        if (!any && t >= 0) break;
+    }
+    for (int i = 1; i < lanes; ++i) {
+        LSR_HIP(hipEventRecord(c.ev_join[i - 1], c.side[i - 1]));
+        LSR_HIP(hipStreamWaitEvent(s, c.ev_join[i - 1], 0));
+    }
+}
+
 // Fused pipeline (caller holds c.mutex): per chunk of witness vectors
 //   top forward round r -> workspace | 12 forward stages x k, A_hat^T product, 12 inverse stages x k -> u | top inverse round (+ e1)
 // with the chunks dealt round-robin to side streams, so that the FP64-bound middle kernel of one chunk runs beside the
@@ -677,6 +771,12 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
     // profiles/r02_commit_split_88.txt): LAMBDA_SNARK_COMMIT_SPLIT=88 — the 8 + 8 split with the barrier-free middle stage —
     // ties with the default 4 + 12 split (3.22-3.31 ms per 1024 rank-4 vectors either way); LAMBDA_SNARK_COMMIT_TWO_LANE=1 adds
     // the two-lane schedule, which is slower today because the outer passes crawl at one workgroup per CU.
+    // default for n = 2^16 with the blinding residues given: mixed launches (one kernel, three roles; see mlwe_matvec_mixed)
+    if (c.logn == 16 && !d_keys && env_int("LAMBDA_SNARK_COMMIT_MIXED", 1, 0, 1) && !env_int("LAMBDA_SNARK_COMMIT_TWO_LANE", 0, 0, 1) &&
+        env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) != 88) {
+        mlwe_matvec_mixed(c, d_r, d_e1, d_u, batch, s);
+        return;
+    }
     if (env_int("LAMBDA_SNARK_COMMIT_TWO_LANE", 0, 0, 1)) {
         mlwe_matvec_two_lane(c, d_r, d_e1, d_u, batch, s, d_keys, c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) == 88);
         return;

@@ -201,17 +201,18 @@ static __global__ void __launch_bounds__(256) f8_permute_matrix_kernel(double* _
     }
 }
 
+// blk: the workgroup's position in the (witness vector, tile) grid — the hardware block index when the stage is a kernel of its
+// own, a number handed out by mlwe_mixed (below) when it is one role of a mixed launch
 template <int K>
-__global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t* __restrict__ rws, uint64_t* __restrict__ u,
-                                                                  const double* __restrict__ a_perm, uint32_t vectors, ModParams p,
-                                                                  const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
+__device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_t* __restrict__ rws, uint64_t* __restrict__ u,
+                                                     const double* __restrict__ a_perm, uint32_t vectors, const ModParams& p,
+                                                     const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
     __shared__ double tile_lds[kF8TileWords];
     __shared__ double tw_lds[kF8TwShared + kF8TwPrivate];
     const uint32_t t = threadIdx.x;
     // (witness vector j, tile).  Workgroups b and b + 8 share an XCD under the observed round-robin placement (speed only):
     // an XCD then sees 2 of the >= 16 tile positions of A_hat, which stay in its L2.
     const int tp_log = p.logn - 12;
-    const uint32_t blk = blockIdx.x;
     const uint32_t rest = blk >> 3;
     const uint32_t tile = (blk & 7u) | ((rest & ((1u << (tp_log - 3)) - 1u)) << 3);
     const uint32_t j = rest >> (tp_log - 3);
@@ -370,6 +371,116 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
         for (int k = 0; k < kF8Regs; ++k) buf_store64<LSR_F8_STORE_AUX>(dst, t * 8u, (uint32_t)k * 4096u, (uint64_t)__double_as_longlong(x[k]));
     });
 }
+
+template <int K>
+__global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t* __restrict__ rws, uint64_t* __restrict__ u,
+                                                                  const double* __restrict__ a_perm, uint32_t vectors, ModParams p,
+                                                                  const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
+    mlwe_mid_fused8_body<K>(blockIdx.x, rws, u, a_perm, vectors, p, fwd_tw, inv_tw);
+}
+
+// =================================================================================================================================
+// MIXED launch (late round 2, n = 2^16, 4 + 12 split).  The three kernels of a chunk are each at their own bound — the strided rounds
+// at the memory system's, the middle stage at FP64 issue — and running them on two streams only makes every kernel slower: the
+// dispatcher hands a CU to whichever kernel has workgroups waiting, the middle stage (two workgroups = the whole register file of a
+// CU) keeps the strided rounds out, and those are latency-bound at the few slots they get (profiles/r02_commit_split_88.txt).
+// Here ONE launch carries the workgroups of three independent pieces of work, in an interleaved block order:
+//     middle stage of chunk c  |  forward strided round of chunk c + 1 (r -> workspace)  |  inverse strided round (+ e1) of chunk c - 1
+// Launches follow each other on one stream, so the dependencies F(c) -> M(c) -> I(c) are launch boundaries and nothing is
+// synchronised inside the kernel.  Every workgroup has the middle stage's shape (512 lanes, 128 VGPRs, 69 KB of LDS: two per CU); a
+// strided-round workgroup plays two of the round's 256-lane groups and ignores the LDS.  The block order (units of 8 workgroups, so
+// that the middle stage keeps its block-index-mod-8 = XCD affinity) decides the mix on a CU: `s_per_m` strided units follow each
+// middle unit, and whenever a slot frees up the next block in line takes it — so a CU mostly holds one FP64-bound and one
+// memory-bound workgroup, and the two pipes of the CU are busy at the same time.
+// =================================================================================================================================
+// forward strided round (top four index bits, out of place, raw out) on G independent 256-lane groups per call: G x 16 loads in
+// flight per lane.  A strided-round workgroup of the mixed launch holds a slot with the middle stage's 128 VGPRs; with one group
+// per lane half of them idle and the round is latency-bound at the few slots it gets.
+template <int G>
+__device__ __forceinline__ void mixed_forward_round(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, size_t total, int lo, const ModParams& p,
+                                                    const double* __restrict__ tw, uint32_t vblock0, uint32_t vthread) {
+    using A = ArithF64;
+    double v[G][16];
+    size_t idx0[G];
+    bool live[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const size_t group = (size_t)(vblock0 + g) * kThreads + vthread;
+        live[g] = group < (total >> 4);
+        const size_t low = group & (((size_t)1 << lo) - 1);
+        idx0[g] = ((group >> lo) << (lo + 4)) | low;
+        if (live[g]) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[g][k] = A::load(__builtin_nontemporal_load(src + idx0[g] + ((size_t)k << lo)), p);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (!live[g]) continue;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const int half = 1 << j;
+#pragma unroll
+            for (int u = 0; u < (1 << (3 - j)); ++u) {
+                const double w = tw[(1 << (3 - j)) + u];
+#pragma unroll
+                for (int l = 0; l < half; ++l) A::ct(v[g][(u << (j + 1)) | l], v[g][((u << (j + 1)) | l) + half], w, p);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dst[idx0[g] + ((size_t)k << lo)] = (uint64_t)__double_as_longlong(v[g][k]);
+    }
+}
+
+struct MixedJob {
+    const uint64_t* m_ws; uint64_t* m_out; uint32_t m_vectors;        // middle stage: workspace -> u (raw), m_vectors witness vectors
+    uint64_t* f_dst; const uint64_t* f_src; uint32_t f_polys;         // forward round: caller's r -> workspace (raw), f_polys polynomials
+    uint64_t* i_data; const uint64_t* i_add; uint32_t i_polys;        // inverse round in place on u (+ i_add, canonical), i_polys polynomials
+    uint32_t units_m, units_f, units_i;                               // units of 8 workgroups per role
+    uint32_t s_per_m, periods;                                        // interleaved part: periods x (1 middle unit + s_per_m strided units)
+    uint32_t f_groups;                                                // 256-lane groups per half workgroup in the forward role: 1 or 2
+};
+
+template <int K>
+__global__ void __launch_bounds__(kF8Threads, 4) mlwe_mixed(MixedJob job, const double* __restrict__ a_perm, ModParams p,
+                                                             const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw,
+                                                             RoundConsts<ArithF64> cs) {
+    const uint32_t x = blockIdx.x >> 3, sub = blockIdx.x & 7u;
+    const uint32_t per = job.s_per_m + 1u, inter = job.periods * per;
+    bool middle;
+    uint32_t unit;                                                    // index within its role class (middle | strided)
+    if (x < inter) {
+        const uint32_t q = x / per, rem = x - q * per;
+        middle = rem == 0;
+        unit = middle ? q : q * job.s_per_m + rem - 1u;
+    } else {
+        const uint32_t y = x - inter, left_m = job.units_m - job.periods;
+        middle = y < left_m;
+        unit = middle ? job.periods + y : job.periods * job.s_per_m + (y - left_m);
+    }
+    if (middle) {
+        mlwe_mid_fused8_body<K>(unit * 8u + sub, job.m_ws, job.m_out, a_perm, job.m_vectors, p, fwd_tw, inv_tw);
+        return;
+    }
+    // strided units: forward and inverse alternate while both last
+    const uint32_t alt = job.units_f < job.units_i ? job.units_f : job.units_i;
+    bool forward;
+    uint32_t idx;
+    if (unit < 2u * alt) { forward = !(unit & 1u); idx = unit >> 1; }
+    else { forward = job.units_f > alt; idx = alt + (unit - 2u * alt); }
+    const uint32_t vblock = (idx * 8u + sub) * 2u + (threadIdx.x >> 8), vthread = threadIdx.x & 255u;
+    const int lo = p.logn - 4;
+    if (forward) {
+        if (job.f_groups == 2) mixed_forward_round<2>(job.f_dst, job.f_src, (size_t)job.f_polys << p.logn, lo, p, fwd_tw, vblock * 2u, vthread);
+        else mixed_forward_round<1>(job.f_dst, job.f_src, (size_t)job.f_polys << p.logn, lo, p, fwd_tw, vblock, vthread);
+    } else if (job.i_add != nullptr)
+        strided_round_body<ArithF64, 4, true, true, false, true, 0>(job.i_data, (size_t)job.i_polys << p.logn, lo, p, inv_tw, cs, job.i_add, BlindSampler{},
+                                                                    vblock, vthread);
+    else
+        strided_round_body<ArithF64, 4, true, true, false, false, 0>(job.i_data, (size_t)job.i_polys << p.logn, lo, p, inv_tw, cs, nullptr, BlindSampler{},
+                                                                     vblock, vthread);
+}
+
 
 
 

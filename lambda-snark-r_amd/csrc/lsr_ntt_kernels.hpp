@@ -340,14 +340,17 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
 template <class A, int R, bool INVERSE, bool RAW_IN, bool RAW_OUT, bool ADD, int SM>
 __device__ __forceinline__ void strided_round_body(uint64_t* __restrict__ data, size_t total, int lo, ModParams p,
                                                    const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
-                                                   const uint64_t* __restrict__ add, const BlindSampler& bs) {
+                                                   const uint64_t* __restrict__ add, const BlindSampler& bs, uint32_t vblock = blockIdx.x,
+                                                   uint32_t vthread = threadIdx.x) {
+    // vblock / vthread: the 256-lane group this call plays (a kernel that hosts the round as ONE of its roles, lsr_commit_fused.hpp
+    // mlwe_mixed, passes its own numbering; sampling modes use the real indices and LDS and are not available there)
     static_assert(!ADD || (INVERSE && !RAW_OUT), "the fused add belongs to the last inverse pass");
     static_assert(SM == 0 || R >= 4, "2^R / 16 blocks per lane and half");
     static_assert((SM != 1 && SM != 2) || ADD, "sampling replaces the read of the blinding residues");
     static_assert(SM != 3 || (!INVERSE && !ADD), "the forward round only prepares samples");
     using elem = typename A::elem;
     constexpr int N = 1 << R;
-    const size_t group = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    const size_t group = (size_t)vblock * kThreads + vthread;
     if (group >= (total >> R)) return;          // whole workgroups: total >> R is a multiple of kThreads (2^lo >= 512)
     const size_t low = group & (((size_t)1 << lo) - 1);
     const size_t idx0 = ((group >> lo) << (lo + R)) | low;

@@ -405,6 +405,41 @@ def test_alternative_commit_pipelines_agree(pkg, oracle, env, monkeypatch):
         lctx.close()
 
 
+@pytest.mark.parametrize("ratio,fgroups,lanes", [("4", "2", "2"), ("2", "1", "1"), ("7", "1", "3")])
+def test_mixed_launch_schedule_agrees(pkg, oracle, ratio, fgroups, lanes, monkeypatch):
+    """LAMBDA_SNARK_COMMIT_MIXED=1: the middle stage of chunk t, the forward strided round of chunk t + 1 and the inverse strided
+    round (+ e1) of chunk t - 1 as roles of one launch (mlwe_mixed).  Ragged batches over one, two and three chunks, ranks 4, 2, 1,
+    several block-order ratios: every word of u equals the default three-launch pipeline's, sampled vectors equal the oracle's."""
+    import torch
+    q, n = 17592182243329, 65536
+    s = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_RATIO", ratio)
+    monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_FGROUPS", fgroups)
+    monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_LANES", lanes)
+    for k, batch in ((4, 150), (4, 64), (4, 5), (2, 70), (1, 299), (3, 65), (4, 33)):
+        lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xFACE + k)
+        a_hat = lctx.public_matrix()
+        d_r = torch.empty((batch, k, n), dtype=torch.int64, device="cuda")
+        assert lctx._lib.lsr_fill_splitmix_device(d_r.data_ptr(), batch, k * n, 0xC0FFEE + 11 * k, q, s) == 0
+        seeds = (np.arange(batch, dtype=np.uint64) + np.uint64(5)) * np.uint64(0x9E3779B9)
+        d_e1 = torch.empty_like(d_r)
+        assert lctx._lib.lsr_lwe_sample_blinding_device(lctx.handle, d_e1.data_ptr(), batch, seeds.ctypes.data, s) == 0
+        d_u0, d_u1 = torch.empty_like(d_r), torch.empty_like(d_r)
+        keep = d_r.clone()
+        monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIXED", "0")
+        assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), d_e1.data_ptr(), d_u0.data_ptr(), batch, None, s) == 0
+        monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIXED", "1")
+        assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), d_e1.data_ptr(), d_u1.data_ptr(), batch, None, s) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(d_r, keep), "the fused pipelines only read r"
+        assert torch.equal(d_u0, d_u1), (k, batch, ratio)
+        for j in sorted({0, min(63, batch - 1), min(64, batch - 1), batch - 1}):
+            r_j = d_r[j].cpu().numpy().view(np.uint64)
+            e1_j = d_e1[j].cpu().numpy().view(np.uint64)
+            assert np.array_equal(d_u1[j].cpu().numpy().view(np.uint64), oracle.mlwe_matvec(q, n, k, a_hat, r_j, e1_j)), (k, batch, j)
+        lctx.close()
+
+
 def test_config3_full_size_device_resident(pkg, oracle):
     """BASELINE config 3 at FULL size: rank 4, n = 2^16, 1024 witness vectors (2 GiB of r), device-resident, through
     lsr_mlwe_matvec_batch_device with e1 drawn by the seeded CDT sampler (sigma = 3.19).  r_j uniform from splitmix64
