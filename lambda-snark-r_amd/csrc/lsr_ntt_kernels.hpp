@@ -169,15 +169,16 @@ __device__ __forceinline__ void inverse_round(typename A::elem (&v)[kRegs], cons
 // one byte offset per mapping, register offsets are immediates, and a partial last tile is clipped by the
 // resource's size (loads return 0, stores are dropped).
 // src (optional): read the operands from there instead of `data` (same layout) — an out-of-place first pass.
+// vblock: the tile this workgroup transforms (the hardware block index when the pass is a kernel of its own)
 template <class A, int LT, bool RAW_IN, bool RAW_OUT>
-__global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restrict__ data, size_t total, ModParams p,
-                                                               const typename A::twid* __restrict__ tw, const uint64_t* __restrict__ src = nullptr) {
+__device__ __forceinline__ void tile_forward_body(uint64_t* __restrict__ data, size_t total, const ModParams& p,
+                                                  const typename A::twid* __restrict__ tw, const uint64_t* __restrict__ src, uint32_t vblock) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
     using twid = typename A::twid;
     constexpr int NR = TileRound<LT, 0>::kCount;
     const uint32_t t = threadIdx.x;
-    const size_t tile_base = (size_t)blockIdx.x * kTile;
+    const size_t tile_base = (size_t)vblock * kTile;
     const uint32_t nmask = (1u << p.logn) - 1u;
     const uint32_t block_pos = (uint32_t)(tile_base & nmask);
     const size_t left = total - tile_base;
@@ -228,21 +229,26 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restric
         buf_store64<RAW_OUT ? 0 : kAuxStream>(tile, t * 8u, (uint32_t)k * kThreads * 8u, RAW_OUT ? bits : A::store_canonical(elem_from_bits<A>(bits), p));
     }
 }
+template <class A, int LT, bool RAW_IN, bool RAW_OUT>
+__global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restrict__ data, size_t total, ModParams p,
+                                                               const typename A::twid* __restrict__ tw, const uint64_t* __restrict__ src = nullptr) {
+    tile_forward_body<A, LT, RAW_IN, RAW_OUT>(data, total, p, tw, src, blockIdx.x);
+}
 
 // `add` (optional, only when !RAW_OUT): canonical residues added to the outputs on the final store — the fused
 // discrete-Gaussian blinding add of the commitment (u = INTT(...) + e1).
 // PRE: every input word is first multiplied by pre[its index within the polynomial] (canonical residues) — a diagonal
 // operator fused into the read-in (the coset twist of the prover's quotient pipeline, lsr_prover.hip).
 template <class A, int LT, bool RAW_IN, bool RAW_OUT, bool PRE = false>
-__global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restrict__ data, size_t total, ModParams p,
-                                                               const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
-                                                               const uint64_t* __restrict__ add, const uint64_t* __restrict__ pre = nullptr) {
+__device__ __forceinline__ void tile_inverse_body(uint64_t* __restrict__ data, size_t total, const ModParams& p,
+                                                  const typename A::twid* __restrict__ tw, const RoundConsts<A>& cs,
+                                                  const uint64_t* __restrict__ add, const uint64_t* __restrict__ pre, uint32_t vblock) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
     using twid = typename A::twid;
     constexpr int NR = TileRound<LT, 0>::kCount;
     const uint32_t t = threadIdx.x;
-    const size_t tile_base = (size_t)blockIdx.x * kTile;
+    const size_t tile_base = (size_t)vblock * kTile;
     const uint32_t nmask = (1u << p.logn) - 1u;
     const uint32_t block_pos = (uint32_t)(tile_base & nmask);
     const size_t left = total - tile_base;
@@ -320,6 +326,12 @@ __global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restric
             __syncthreads();
         }
     });
+}
+template <class A, int LT, bool RAW_IN, bool RAW_OUT, bool PRE = false>
+__global__ void __launch_bounds__(kThreads) ntt_tile_inverse(uint64_t* __restrict__ data, size_t total, ModParams p,
+                                                               const typename A::twid* __restrict__ tw, RoundConsts<A> cs,
+                                                               const uint64_t* __restrict__ add, const uint64_t* __restrict__ pre = nullptr) {
+    tile_inverse_body<A, LT, RAW_IN, RAW_OUT, PRE>(data, total, p, tw, cs, add, pre, blockIdx.x);
 }
 
 // ---- strided round kernel (the TOP R index bits: lo + R == log n) ------------------------------------
