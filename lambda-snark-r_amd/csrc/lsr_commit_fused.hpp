@@ -462,6 +462,10 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mixed(MixedJob job, const 
         mlwe_mid_fused8_body<K>(unit * 8u + sub, job.m_ws, job.m_out, a_perm, job.m_vectors, p, fwd_tw, inv_tw);
         return;
     }
+    // the strided roles issue ahead of the middle stage's waves on their SIMD: their few instructions put loads and stores in flight,
+    // and the sooner a strided workgroup is through, the sooner its slot is free (2.92-2.96 vs 2.98-2.99 ms per 1024 vectors; the
+    // opposite priority loses: profiles/r02_mixed_launch.txt)
+    __builtin_amdgcn_s_setprio(3);
     // strided units: forward and inverse alternate while both last
     const uint32_t alt = job.units_f < job.units_i ? job.units_f : job.units_i;
     bool forward;
