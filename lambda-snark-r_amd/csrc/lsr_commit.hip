@@ -669,11 +669,15 @@ static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const
 // kernel (lsr_commit_fused.hpp, mlwe_mixed), t = -1 .. chunks; two workspace slots alternate.  One stream, no events: the launch
 // boundaries are the dependencies.
 template <int K>
-static void launch_mixed(const LweContext& c, const MixedJob& job, hipStream_t s) {
+static void launch_mixed(const LweContext& c, const MixedJob& job, hipStream_t s, bool split88) {
     const unsigned grid = (job.units_m + job.units_f + job.units_i) * 8u;
     if (!grid) return;
-    hipLaunchKernelGGL((mlwe_mixed<K>), dim3(grid), dim3(kF8Threads), 0, s, job, c.a_perm.ptr, c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr,
-                       RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64});
+    if (split88)
+        hipLaunchKernelGGL((mlwe_mixed88<K>), dim3(grid), dim3(512), 0, s, job, c.a_perm8.ptr, c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr,
+                           RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64});
+    else
+        hipLaunchKernelGGL((mlwe_mixed<K>), dim3(grid), dim3(kF8Threads), 0, s, job, c.a_perm.ptr, c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr,
+                           RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64});
     LSR_HIP(hipGetLastError());
 }
 
@@ -704,7 +708,9 @@ static void mlwe_matvec_mixed(const LweContext& c, const uint64_t* d_r, const ui
     // XCDs and their CUs round-robin, and with an even period the middle-stage workgroups pile up on a fraction of the CUs
     // (profiles/r02_mixed_launch.txt: ratio 3 -> 5.5 ms, ratio 2 -> 3.07 ms per 1024 vectors)
     const int ratio = env_int("LAMBDA_SNARK_COMMIT_MIX_RATIO", 4, 1, 64);
-    const int fgroups = env_int("LAMBDA_SNARK_COMMIT_MIX_FGROUPS", 2, 1, 2);
+    // LAMBDA_SNARK_COMMIT_MIX_SPLIT=88: the roles of the 8 + 8 split (mlwe_mixed88) instead of the 4 + 12 split's
+    const bool split88 = c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_MIX_SPLIT", 412, 0, 412) == 88;
+    const int fgroups = split88 ? 1 : env_int("LAMBDA_SNARK_COMMIT_MIX_FGROUPS", 2, 1, 2);
     for (long t = -1;; ++t) {
         bool any = false;
         for (int lane = 0; lane < lanes; ++lane) {
@@ -744,10 +750,10 @@ static void mlwe_matvec_mixed(const LweContext& c, const uint64_t* d_r, const ui
             }
             hipStream_t st = lane == 0 ? s : c.side[lane - 1];
             switch (k) {
-                case 1: launch_mixed<1>(c, job, st); break;
-                case 2: launch_mixed<2>(c, job, st); break;
-                case 3: launch_mixed<3>(c, job, st); break;
-                default: launch_mixed<4>(c, job, st); break;
+                case 1: launch_mixed<1>(c, job, st, split88); break;
+                case 2: launch_mixed<2>(c, job, st, split88); break;
+                case 3: launch_mixed<3>(c, job, st, split88); break;
+                default: launch_mixed<4>(c, job, st, split88); break;
             }
         }
         if (!any && t >= 0) break;

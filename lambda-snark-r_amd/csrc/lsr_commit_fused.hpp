@@ -517,13 +517,12 @@ template <int COLS> constexpr uint32_t c8_lds_words() { return 256u * COLS + (CO
 // forward: stages of polynomial index bits 15..8 on a tile of COLS adjacent columns x 256 rows (bits 8..15)
 // STREAM: every global access with the nt policy, so that the pass leaves the XCD's L2 to a co-resident middle stage (two-lane schedule)
 template <bool STREAM, int COLS>
-__global__ void __launch_bounds__(COLS * 16) cols8_forward(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t polys, ModParams p,
-                                                           const double* __restrict__ tw) {
-    __shared__ double lds[c8_lds_words<COLS>()];
+__device__ __forceinline__ void cols8_forward_body(uint32_t blk, uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t polys,
+                                                   const ModParams& p, const double* __restrict__ tw, double* __restrict__ lds) {
     using A = ArithF64;
     constexpr uint32_t CB = 256 / COLS;
     const uint32_t t = threadIdx.x;
-    const uint32_t poly = blockIdx.x / CB, cb = blockIdx.x % CB;
+    const uint32_t poly = blk / CB, cb = blk % CB;
     if (poly >= polys) return;
     const uint32_t col = t % COLS, rr = t / COLS;
     const size_t base = ((size_t)poly << 16) + cb * COLS + col;
@@ -567,16 +566,22 @@ __global__ void __launch_bounds__(COLS * 16) cols8_forward(uint64_t* __restrict_
         else *at = (uint64_t)__double_as_longlong(v[k]);
     }
 }
+template <bool STREAM, int COLS>
+__global__ void __launch_bounds__(COLS * 16) cols8_forward(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t polys, ModParams p,
+                                                           const double* __restrict__ tw) {
+    __shared__ double lds[c8_lds_words<COLS>()];
+    cols8_forward_body<STREAM, COLS>(blockIdx.x, dst, src, polys, p, tw, lds);
+}
 
 // inverse: stages of bits 8..15 (Gentleman–Sande), n^-1 folded into the last one, + add (canonical residues, optional), canonical out
 template <bool STREAM, int COLS>
-__global__ void __launch_bounds__(COLS * 16) cols8_inverse(uint64_t* __restrict__ data, uint32_t polys, ModParams p, const double* __restrict__ tw,
-                                                           RoundConsts<ArithF64> cs, const uint64_t* __restrict__ add) {
-    __shared__ double lds[c8_lds_words<COLS>()];
+__device__ __forceinline__ void cols8_inverse_body(uint32_t blk, uint64_t* __restrict__ data, uint32_t polys, const ModParams& p,
+                                                   const double* __restrict__ tw, const RoundConsts<ArithF64>& cs, const uint64_t* __restrict__ add,
+                                                   double* __restrict__ lds) {
     using A = ArithF64;
     constexpr uint32_t CB = 256 / COLS;
     const uint32_t t = threadIdx.x;
-    const uint32_t poly = blockIdx.x / CB, cb = blockIdx.x % CB;
+    const uint32_t poly = blk / CB, cb = blk % CB;
     if (poly >= polys) return;
     const uint32_t col = t % COLS, rr = t / COLS;
     const size_t base = ((size_t)poly << 16) + cb * COLS + col;
@@ -625,6 +630,12 @@ __global__ void __launch_bounds__(COLS * 16) cols8_inverse(uint64_t* __restrict_
         const uint64_t out = add != nullptr ? A::store_reduced_plus(v[k], blind[k], p) : A::store_reduced(v[k], p);
         __builtin_nontemporal_store(out, data + base + ((uint32_t)k << 12) + (rr << 8));
     }
+}
+template <bool STREAM, int COLS>
+__global__ void __launch_bounds__(COLS * 16) cols8_inverse(uint64_t* __restrict__ data, uint32_t polys, ModParams p, const double* __restrict__ tw,
+                                                           RoundConsts<ArithF64> cs, const uint64_t* __restrict__ add) {
+    __shared__ double lds[c8_lds_words<COLS>()];
+    cols8_inverse_body<STREAM, COLS>(blockIdx.x, data, polys, p, tw, cs, add, lds);
 }
 
 // ---- the middle stage ----
@@ -756,17 +767,15 @@ static __global__ void __launch_bounds__(256) m8_permute_matrix_kernel(double* _
 template <int WAVES> constexpr uint32_t m8_lds_words() { return WAVES == 8 ? 2 * m8_image_words<8>() : 41472u / 8u; }
 
 template <int K, int WAVES>
-__device__ __forceinline__ void mlwe_mid8_body(const uint64_t* __restrict__ rws, uint64_t* __restrict__ u, const double* __restrict__ a_perm,
+__device__ __forceinline__ void mlwe_mid8_body(uint32_t blk, const uint64_t* __restrict__ rws, uint64_t* __restrict__ u, const double* __restrict__ a_perm,
                                                uint32_t vectors, const ModParams& p, const double* __restrict__ fwd_tw,
-                                               const double* __restrict__ inv_tw) {
+                                               const double* __restrict__ inv_tw, double* __restrict__ image_lds) {
     static_assert(2 * m8_image_words<WAVES>() <= m8_lds_words<WAVES>(), "twiddle images must fit");
     constexpr int WB = m8_wave_bits<WAVES>();
-    __shared__ double image_lds[m8_lds_words<WAVES>()];
     const double* image = image_lds;                              // forward half first, inverse half for the second phase
     const uint32_t t = threadIdx.x;
     // (witness vector j, tile, half).  Workgroups b and b + 8 share an XCD under the observed round-robin placement (speed only):
     // an XCD sees tiles {x, x + 8}, 1 MiB of a_perm8, which stays in its L2.
-    const uint32_t blk = blockIdx.x;
     uint32_t rest = blk >> 3;
     const uint32_t tile = (blk & 7u) | ((rest & 1u) << 3);        // n = 2^16: 16 tiles per polynomial
     rest >>= 1;
@@ -874,15 +883,52 @@ __device__ __forceinline__ void mlwe_mid8_body(const uint64_t* __restrict__ rws,
 template <int K>
 __global__ void __launch_bounds__(512, 4) mlwe_mid8_w8(const uint64_t* __restrict__ rws, uint64_t* __restrict__ u, const double* __restrict__ a_perm,
                                                        uint32_t vectors, ModParams p, const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
-    mlwe_mid8_body<K, 8>(rws, u, a_perm, vectors, p, fwd_tw, inv_tw);
+    __shared__ double image_lds[m8_lds_words<8>()];
+    mlwe_mid8_body<K, 8>(blockIdx.x, rws, u, a_perm, vectors, p, fwd_tw, inv_tw, image_lds);
 }
 // 136 VGPRs: three of these waves per SIMD leave 512 - 3 x 136 = 104 registers, what one wave of cols8_inverse needs
 template <int K>
 __global__ void __launch_bounds__(256, 3) __attribute__((amdgpu_num_vgpr(136)))
 mlwe_mid8_w4(const uint64_t* __restrict__ rws, uint64_t* __restrict__ u, const double* __restrict__ a_perm, uint32_t vectors, ModParams p,
              const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
-    mlwe_mid8_body<K, 4>(rws, u, a_perm, vectors, p, fwd_tw, inv_tw);
+    __shared__ double image_lds[m8_lds_words<4>()];
+    mlwe_mid8_body<K, 4>(blockIdx.x, rws, u, a_perm, vectors, p, fwd_tw, inv_tw, image_lds);
 }
 
+
+// Mixed launch of the 8 + 8 split (same scheme and block order as mlwe_mixed): roles = barrier-free middle stage mlwe_mid8 (bits 7..0),
+// cols8_forward of the next chunk, cols8_inverse (+ e1) of the previous one — all 512-lane workgroups, 64-65 KB of LDS.
+// a_perm8 layout.  `job.f_groups` is ignored (one 32-column tile per workgroup).
+template <int K>
+__global__ void __launch_bounds__(512, 4) mlwe_mixed88(MixedJob job, const double* __restrict__ a_perm8, ModParams p, const double* __restrict__ fwd_tw,
+                                                       const double* __restrict__ inv_tw, RoundConsts<ArithF64> cs) {
+    constexpr uint32_t kPool = m8_lds_words<8>() > c8_lds_words<32>() ? m8_lds_words<8>() : c8_lds_words<32>();
+    __shared__ double pool[kPool];                                    // one LDS block, whichever role the workgroup plays
+    const uint32_t x = blockIdx.x >> 3, sub = blockIdx.x & 7u;
+    const uint32_t per = job.s_per_m + 1u, inter = job.periods * per;
+    bool middle;
+    uint32_t unit;
+    if (x < inter) {
+        const uint32_t q = x / per, rem = x - q * per;
+        middle = rem == 0;
+        unit = middle ? q : q * job.s_per_m + rem - 1u;
+    } else {
+        const uint32_t y = x - inter, left_m = job.units_m - job.periods;
+        middle = y < left_m;
+        unit = middle ? job.periods + y : job.periods * job.s_per_m + (y - left_m);
+    }
+    if (middle) {
+        mlwe_mid8_body<K, 8>(unit * 8u + sub, job.m_ws, job.m_out, a_perm8, job.m_vectors, p, fwd_tw, inv_tw, pool);
+        return;
+    }
+    const uint32_t alt = job.units_f < job.units_i ? job.units_f : job.units_i;
+    bool forward;
+    uint32_t idx;
+    if (unit < 2u * alt) { forward = !(unit & 1u); idx = unit >> 1; }
+    else { forward = job.units_f > alt; idx = alt + (unit - 2u * alt); }
+    __builtin_amdgcn_s_setprio(3);
+    if (forward) cols8_forward_body<false, 32>(idx * 8u + sub, job.f_dst, job.f_src, job.f_polys, p, fwd_tw, pool);
+    else cols8_inverse_body<false, 32>(idx * 8u + sub, job.i_data, job.i_polys, p, inv_tw, cs, job.i_add, pool);
+}
 
 }  // namespace lsr

@@ -405,10 +405,11 @@ def test_alternative_commit_pipelines_agree(pkg, oracle, env, monkeypatch):
         lctx.close()
 
 
-@pytest.mark.parametrize("ratio,fgroups,lanes", [("4", "2", "2"), ("2", "1", "1"), ("7", "1", "3")])
-def test_mixed_launch_schedule_agrees(pkg, oracle, ratio, fgroups, lanes, monkeypatch):
+@pytest.mark.parametrize("ratio,fgroups,lanes,split", [("4", "2", "2", "412"), ("2", "1", "1", "412"), ("7", "1", "3", "412"), ("4", "1", "2", "88"),
+                                                        ("2", "1", "1", "88")])
+def test_mixed_launch_schedule_agrees(pkg, oracle, ratio, fgroups, lanes, split, monkeypatch):
     """LAMBDA_SNARK_COMMIT_MIXED=1: the middle stage of chunk t, the forward strided round of chunk t + 1 and the inverse strided
-    round (+ e1) of chunk t - 1 as roles of one launch (mlwe_mixed).  Ragged batches over one, two and three chunks, ranks 4, 2, 1,
+    round (+ e1) of chunk t - 1 as roles of one launch (mlwe_mixed; with MIX_SPLIT=88 the roles of the 8 + 8 split, mlwe_mixed88).  Ragged batches over one, two and three chunks, ranks 4, 2, 1,
     several block-order ratios: every word of u equals the default three-launch pipeline's, sampled vectors equal the oracle's."""
     import torch
     q, n = 17592182243329, 65536
@@ -416,6 +417,7 @@ def test_mixed_launch_schedule_agrees(pkg, oracle, ratio, fgroups, lanes, monkey
     monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_RATIO", ratio)
     monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_FGROUPS", fgroups)
     monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_LANES", lanes)
+    monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_SPLIT", split)
     for k, batch in ((4, 150), (4, 64), (4, 5), (2, 70), (1, 299), (3, 65), (4, 33)):
         lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xFACE + k)
         a_hat = lctx.public_matrix()
