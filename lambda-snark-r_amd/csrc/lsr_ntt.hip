@@ -358,6 +358,32 @@ void launch_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hi
     LSR_HIP(hipGetLastError());
 }
 
+// Forward transform of a Goldilocks batch (n <= 4096: one tile launch) with elementwise work of the prover's quotient pipeline
+// fused into its read-in (lsr_ntt_kernels.hpp, FuseIn): mode 1 = operands multiplied by x1 first, mode 2 = a b == c tested on the way in.
+template <int MODE>
+static void fused_forward(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* src, const FuseIn& fuse) {
+    const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
+    const auto* tw = Flavour<ArithGold>::fwd(c);
+#define LSR_FUSED_CASE(LT) case LT: hipLaunchKernelGGL((ntt_tile_forward_fused<ArithGold, LT, MODE>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, tw, src, fuse); break;
+    switch (c.logn) {
+        LSR_FUSED_CASE(1) LSR_FUSED_CASE(2) LSR_FUSED_CASE(3) LSR_FUSED_CASE(4) LSR_FUSED_CASE(5) LSR_FUSED_CASE(6)
+        LSR_FUSED_CASE(7) LSR_FUSED_CASE(8) LSR_FUSED_CASE(9) LSR_FUSED_CASE(10) LSR_FUSED_CASE(11)
+        default: hipLaunchKernelGGL((ntt_tile_forward_fused<ArithGold, 12, MODE>), dim3(grid), dim3(kThreads), 0, s, d, total, c.mod, tw, src, fuse); break;
+    }
+#undef LSR_FUSED_CASE
+}
+bool ntt_forward_can_fuse(const NttContext& c) { return c.gold && c.logn >= 1 && c.logn <= kTileLog; }
+void launch_ntt_forward_fused(const NttContext& c, uint64_t* d, size_t batch, hipStream_t s, const uint64_t* src, int mode, const uint64_t* x1,
+                              const uint64_t* x2, uint32_t* bad) {
+    if (!ntt_forward_can_fuse(c) || (mode != 1 && mode != 2) || !x1 || (mode == 2 && (!x2 || !bad)))
+        throw std::runtime_error("fused forward transform: Goldilocks context with n <= 4096, mode 1 or 2");
+    const size_t total = batch << c.logn;
+    if (!total) return;
+    if (mode == 1) fused_forward<1>(c, d, total, s, src, FuseIn{x1, nullptr, nullptr});
+    else fused_forward<2>(c, d, total, s, src, FuseIn{x1, x2, bad});
+    LSR_HIP(hipGetLastError());
+}
+
 // The strided (top index bits) round of an n > 4096 transform on its own: the outer passes of the fused commitment
 // pipeline (lsr_commit.hip), whose middle stage replaces the tile kernels.  FP64 flavour.
 void launch_top_round_forward(const NttContext& c, uint64_t* dst, const uint64_t* src, size_t polys, hipStream_t s) {

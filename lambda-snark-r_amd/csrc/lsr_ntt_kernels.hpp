@@ -170,9 +170,19 @@ __device__ __forceinline__ void inverse_round(typename A::elem (&v)[kRegs], cons
 // resource's size (loads return 0, stores are dropped).
 // src (optional): read the operands from there instead of `data` (same layout) — an out-of-place first pass.
 // vblock: the tile this workgroup transforms (the hardware block index when the pass is a kernel of its own)
-template <class A, int LT, bool RAW_IN, bool RAW_OUT>
+// Elementwise work fused into the read-in of a forward tile pass (the prover's quotient pipeline, lsr_prover.hip; Goldilocks only):
+//   MODE 1: every operand is first multiplied by the word of `x1` at the same index (standard form) — the coset product a b;
+//   MODE 2: the operands are the c_k of R1CS constraints and x1 = a, x2 = b: a_k b_k == c_k is tested on the way in, a failing
+//           constraint marks its instance in `bad` (is_satisfied, r1cs.rs:148-172).  The transform itself is unchanged.
+struct FuseIn {
+    const uint64_t* x1 = nullptr;
+    const uint64_t* x2 = nullptr;
+    uint32_t* bad = nullptr;
+};
+template <class A, int LT, bool RAW_IN, bool RAW_OUT, int MODE = 0>
 __device__ __forceinline__ void tile_forward_body(uint64_t* __restrict__ data, size_t total, const ModParams& p,
-                                                  const typename A::twid* __restrict__ tw, const uint64_t* __restrict__ src, uint32_t vblock) {
+                                                  const typename A::twid* __restrict__ tw, const uint64_t* __restrict__ src, uint32_t vblock,
+                                                  const FuseIn& fuse = FuseIn{}) {
     __shared__ uint64_t lds[kLdsWords];
     using elem = typename A::elem;
     using twid = typename A::twid;
@@ -196,8 +206,32 @@ __device__ __forceinline__ void tile_forward_body(uint64_t* __restrict__ data, s
 #pragma unroll
         for (int k = 0; k < kRegs; ++k) raw[k] = buf_load64<RAW_OUT ? 0 : kAuxStream>(from, base * 8u, reg_offset<LO, R>(k) * 8u);
         load_round_twiddles<A, LO, R, false, false>(w[0], base, block_pos, nmask, p.logn, table);
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < kRegs; ++k) v[k] = RAW_IN ? elem_from_bits<A>(raw[k]) : A::load(raw[k], p);
+            for (int k = 0; k < kRegs; ++k) v[k] = RAW_IN ? elem_from_bits<A>(raw[k]) : A::load(raw[k], p);
+        } else {
+            static_assert(std::is_same_v<A, ArithGold> && !RAW_IN, "fused elementwise work: first pass of a Goldilocks transform");
+            const rsrc_t r1 = make_rsrc(fuse.x1 + tile_base, tile_bytes);
+            uint64_t o1[kRegs];
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k) o1[k] = buf_load64(r1, base * 8u, reg_offset<LO, R>(k) * 8u);
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < kRegs; ++k) v[k] = gold_mul(A::load(raw[k], p), A::load(o1[k], p));
+            } else {
+                const rsrc_t r2 = make_rsrc(fuse.x2 + tile_base, tile_bytes);
+                uint64_t o2[kRegs];
+#pragma unroll
+                for (int k = 0; k < kRegs; ++k) o2[k] = buf_load64(r2, base * 8u, reg_offset<LO, R>(k) * 8u);
+#pragma unroll
+                for (int k = 0; k < kRegs; ++k) {
+                    v[k] = A::load(raw[k], p);
+                    const uint32_t at = base + reg_offset<LO, R>(k);                    // index within the tile
+                    if (at * 8u < tile_bytes && gold_mul(A::load(o1[k], p), A::load(o2[k], p)) != v[k])
+                        atomicOr(&fuse.bad[(tile_base + at) >> p.logn], 1u);             // only ever taken for an unsatisfied instance
+                }
+            }
+        }
     }
 
     static_for<0, NR>([&](auto ic) {
@@ -233,6 +267,11 @@ template <class A, int LT, bool RAW_IN, bool RAW_OUT>
 __global__ void __launch_bounds__(kThreads) ntt_tile_forward(uint64_t* __restrict__ data, size_t total, ModParams p,
                                                                const typename A::twid* __restrict__ tw, const uint64_t* __restrict__ src = nullptr) {
     tile_forward_body<A, LT, RAW_IN, RAW_OUT>(data, total, p, tw, src, blockIdx.x);
+}
+template <class A, int LT, int MODE>
+__global__ void __launch_bounds__(kThreads) ntt_tile_forward_fused(uint64_t* __restrict__ data, size_t total, ModParams p,
+                                                                     const typename A::twid* __restrict__ tw, const uint64_t* __restrict__ src, FuseIn fuse) {
+    tile_forward_body<A, LT, false, false, MODE>(data, total, p, tw, src, blockIdx.x, fuse);
 }
 
 // `add` (optional, only when !RAW_OUT): canonical residues added to the outputs on the final store — the fused

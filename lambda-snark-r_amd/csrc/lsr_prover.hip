@@ -218,18 +218,29 @@ static void quotient_pass(LsrQuotientPlan& p, const uint64_t* d_a, const uint64_
     uint32_t* top = p.flags.ptr;
     uint32_t* bad = p.flags.ptr + count;
     LSR_HIP(hipMemsetAsync(p.flags.ptr, 0, 2 * count * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(check_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, d_a, d_b, d_c, bad, p.logm, per_vector);
+    // m <= 4096 (one tile launch per transform): the two elementwise kernels ride in the read-in of a transform — the a b = c test in
+    // C's interpolation, the coset product in the last transform (the transforms are integer-VALU-bound, the extra loads cost nothing
+    // and two passes over the planes disappear: profiles/r02b_quotient_fusion.txt).  LAMBDA_SNARK_QUOTIENT_FUSE=0 keeps them apart.
+    const char* const fuse_env = std::getenv("LAMBDA_SNARK_QUOTIENT_FUSE");
+    const bool fuse = !(fuse_env && fuse_env[0] == '0') && p.ntt && ntt_forward_can_fuse(*p.ntt);
+    const bool fuse_check = fuse && d_a != work;
+    if (!fuse_check) hipLaunchKernelGGL(check_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, d_a, d_b, d_c, bad, p.logm, per_vector);
     if (p.ntt) {
         if (d_a == work) {                                                               // interpolation: r1cs.rs:489-491
             launch_ntt(*p.ntt, work, 3 * count, false, s);
         } else {   // out of place: the caller's arrays are read, the workspace planes written
             launch_ntt(*p.ntt, work, count, false, s, nullptr, nullptr, d_a);
             launch_ntt(*p.ntt, work + per_vector, count, false, s, nullptr, nullptr, d_b);
-            launch_ntt(*p.ntt, work + 2 * per_vector, count, false, s, nullptr, nullptr, d_c);
+            if (fuse_check) launch_ntt_forward_fused(*p.ntt, work + 2 * per_vector, count, s, d_c, 2, d_a, d_b, bad);
+            else launch_ntt(*p.ntt, work + 2 * per_vector, count, false, s, nullptr, nullptr, d_c);
         }
         launch_ntt(*p.ntt, work, 2 * count, true, s, nullptr, p.twist.ptr);              // A, B on the coset psi H
-        hipLaunchKernelGGL(product_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, work + per_vector, per_vector);   // r1cs.rs:495
-        launch_ntt(*p.ntt, work, count, false, s);                                       // back to (twisted, bit-reversed) coefficients
+        if (fuse) {
+            launch_ntt_forward_fused(*p.ntt, work, count, s, nullptr, 1, work + per_vector, nullptr, nullptr);   // (a b) -> coefficients, r1cs.rs:495
+        } else {
+            hipLaunchKernelGGL(product_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, work + per_vector, per_vector);   // r1cs.rs:495
+            launch_ntt(*p.ntt, work, count, false, s);                                   // back to (twisted, bit-reversed) coefficients
+        }
         if (p.logm >= 12) {
             hipLaunchKernelGGL(finish_quotient_kernel<true>, dim3(static_cast<unsigned>(per_vector / kSplitTile)), dim3(kBlock), 0, s, work,
                                work + 2 * per_vector, p.untwist.ptr, p.half_m_inv, d_q, top, p.logm, per_vector);

@@ -118,6 +118,11 @@ void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inve
                 const uint64_t* forward_source = nullptr);
 // only the strided top-bits round of an n > 4096 FP64-flavour transform: forward reads canonical `src`, writes raw elements
 // to `dst` (may alias); inverse turns raw elements into canonical residues (+ optional canonical `add`), in place
+// forward transform (Goldilocks, n <= 4096) with elementwise work fused into the read-in: mode 1 = multiply by x1 first (src may be
+// NULL = in place), mode 2 = test x1 * x2 == operand and mark failing instances in bad[index >> log n]
+bool ntt_forward_can_fuse(const NttContext& ctx);
+void launch_ntt_forward_fused(const NttContext& ctx, uint64_t* d_data, size_t batch, hipStream_t stream, const uint64_t* src, int mode, const uint64_t* x1,
+                              const uint64_t* x2, uint32_t* bad);
 void launch_top_round_forward(const NttContext& ctx, uint64_t* d_dst, const uint64_t* d_src, size_t polys, hipStream_t stream);
 void launch_top_round_inverse(const NttContext& ctx, uint64_t* d_data, size_t polys, hipStream_t stream, const uint64_t* add);
 // the same round with the added residues sampled in the pass (CDT Gaussian per polynomial, lsr_sampler.hpp) instead of read

@@ -239,6 +239,41 @@ def test_quotient_device_api_and_chunking(pkg, oracle, monkeypatch):
     plan.close()
 
 
+@pytest.mark.parametrize("m", [2, 64, 4096])
+def test_quotient_fused_elementwise_stages_agree(pkg, oracle, m, monkeypatch):
+    """m <= 4096: the a b = c test rides in the read-in of C's interpolation and the coset product in the read-in of the last
+    transform (LAMBDA_SNARK_QUOTIENT_FUSE, default on).  Device API, words >= p among the inputs, spoiled instances: lengths and
+    quotients equal those of the separate kernels and the oracle's."""
+    import torch
+    batch = 600 if m < 4096 else 40
+    rng = np.random.default_rng(4242 + m)
+    spoil = (0, 7, batch - 1)
+    a, b, c = instances(rng, m, batch, spoil=spoil)
+    for v in (a, b, c):                           # non-canonical representatives of small residues
+        small = v < np.uint64(2**32 - 1)
+        v[small] = v[small] + np.uint64(Q)
+    plan = pkg.QuotientPlan(m, device=0)
+    da, db, dc = (torch.from_numpy(v.view(np.int64)).cuda() for v in (a, b, c))
+    s = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("LAMBDA_SNARK_QUOTIENT_FUSE", fuse)
+        dq = torch.zeros_like(da)
+        dl = torch.full((batch,), -1, dtype=torch.int32, device="cuda")
+        plan.quotient_device(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, dq.data_ptr(), dl.data_ptr(), s)
+        torch.cuda.synchronize()
+        out[fuse] = (dq.cpu().numpy().view(np.uint64), dl.cpu().numpy().view(np.uint32))
+    assert np.array_equal(out["1"][1], out["0"][1])
+    lens = out["1"][1]
+    assert all(lens[i] == 0 for i in spoil) and (np.delete(lens, list(spoil)) >= 1).all()
+    ok = lens > 0
+    assert np.array_equal(out["1"][0][ok], out["0"][0][ok])
+    for i in (1, batch // 2, batch - 2):
+        want, ln = oracle.quotient(a[i] % np.uint64(Q), b[i] % np.uint64(Q), c[i] % np.uint64(Q))
+        assert lens[i] == ln and np.array_equal(out["1"][0][i], want)
+    plan.close()
+
+
 # ---- compute_quotient_poly(witness) in full: sparse products + pipeline -------------------------------------------------
 def random_r1cs(rng, m, free_vars, fan_in=3):
     """m constraints (A_i.z)(B_i.z) = z[free_vars + i] over free_vars + m variables; A_i, B_i touch earlier variables only,
