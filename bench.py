@@ -357,6 +357,17 @@ def main():
         t_v = wall(lambda: flat_lib.lsr_lwe_verify_opening_batch_flat(rctx.handle, rows.ctypes.data, rmsgs.ctypes.data, 8, nb, verdicts.ctypes.data))
         extra.update({"ref_params_commits_per_s_pcie": nb / t_c, "ref_params_openings_per_s_pcie": nb / t_v,
                       "ref_params_all_verified": bool((verdicts == 1).all())})
+        # the same two calls with the rows in page-locked host memory (lsr_host_alloc_pinned): the copy back is then one DMA
+        try:
+            pin = pkg.PinnedArray(rows.shape)
+            t_cp = wall(lambda: flat_lib.lsr_lwe_commit_batch_flat(rctx.handle, rmsgs.ctypes.data, 8, nb, rseeds.ctypes.data, pin.ptr))
+            verdicts[:] = 0
+            t_vp = wall(lambda: flat_lib.lsr_lwe_verify_opening_batch_flat(rctx.handle, pin.ptr, rmsgs.ctypes.data, 8, nb, verdicts.ctypes.data))
+            extra.update({"ref_params_commits_per_s_pcie_pinned": nb / t_cp, "ref_params_openings_per_s_pcie_pinned": nb / t_vp,
+                          "ref_params_pinned_rows_equal": bool(np.array_equal(pin.array, rows)) and bool((verdicts == 1).all())})
+            pin.close()
+        except Exception as exc:      # informational
+            extra["ref_params_pinned_error"] = f"{type(exc).__name__}: {exc}"
         rctx.close()
 
     # ---- config 4: the config-3 batch cut into contiguous slices over the node's GPUs INSIDE the library (one host thread and

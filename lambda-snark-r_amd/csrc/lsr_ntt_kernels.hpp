@@ -299,8 +299,13 @@ __device__ __forceinline__ void tile_inverse_body(uint64_t* __restrict__ data, s
 
     {   // coalesced read-in to LDS (raw element bits); the first round's twiddles ride along
         uint64_t raw[kRegs];
+        // single-pass inverse transforms (n <= 4096): a fresh workgroup puts its loads in flight ahead of its neighbours' arithmetic
+        // (-4 % at n = 4096; the same in the forward kernel or in the passes of a two-pass transform loses 2-3 %: profiles/r02b_tile_prio.txt)
+        constexpr bool kLoadPrio = !RAW_IN && !RAW_OUT;
+        if constexpr (kLoadPrio) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int k = 0; k < kRegs; ++k) raw[k] = buf_load64<RAW_OUT ? 0 : kAuxStream>(tile, t * 8u, (uint32_t)k * kThreads * 8u);
+        if constexpr (kLoadPrio) __builtin_amdgcn_s_setprio(0);
         constexpr int J = NR - 1;
         constexpr int LO = TileRound<LT, J>::LO, R = TileRound<LT, J>::R;
         load_round_twiddles<A, LO, R, true, (NR == 1) && !RAW_OUT>(w[0], lane_base<LO, R>(t), block_pos, nmask, p.logn, table);
