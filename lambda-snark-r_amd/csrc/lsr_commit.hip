@@ -387,7 +387,7 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
         DeviceGuard guard(c->device);
         const std::vector<uint64_t> table = gaussian_cdf(c->sigma);
         c->cdf.upload(table);
-        c->cdf_entries = static_cast<uint32_t>(table.size());
+        c->cdf_entries = gaussian_scan_entries(table);   // the saturated tail of the table never changes a 63-bit scan
         c->key_seed = key_seed;
         c->keys = replicate ? *replicate : derive_context_keys(key_seed);
         const size_t kn = (size_t)k * n;

@@ -181,6 +181,12 @@ std::vector<uint64_t> gaussian_cdf(double sigma) {
     return cdf;
 }
 
+uint32_t gaussian_scan_entries(const std::vector<uint64_t>& cdf) {
+    size_t first = 0;
+    while (first < cdf.size() && (cdf[first] >> 1) != 0x7FFFFFFFFFFFFFFFull) ++first;
+    return static_cast<uint32_t>(std::min(cdf.size(), first + 1));
+}
+
 uint64_t select_commit_modulus(uint64_t requested, uint32_t n) {
     if (n < 2 || (n & (n - 1)) != 0 || n > 131072) return 0;
     const bool usable = requested >= (1ull << 40) && requested < (1ull << 61) &&

@@ -58,6 +58,10 @@ inline uint64_t shoup_quotient(uint64_t w, uint64_t q) { return (uint64_t)(((u12
 
 // CDT table of the reference sampler (cpp-core/src/utils.cpp:26-75). Empty on invalid sigma.
 std::vector<uint64_t> gaussian_cdf(double sigma);
+// Entries of `cdf` a scan at 63-bit precision has to visit: everything from the first entry whose upper 63 bits are all ones on
+// can never be below a 63-bit uniform value, so `count += (cdf[k] >> 1 < u)` stops changing there (sigma = 3.19: 30 of 40).  The
+// scan loops over k + 1 < entries, hence first saturated index + 1.  Same samples, bit for bit.
+uint32_t gaussian_scan_entries(const std::vector<uint64_t>& cdf);
 
 // Commitment parameter selection (DESIGN.md "Commitment definition").
 uint64_t select_commit_modulus(uint64_t requested, uint32_t n);

@@ -107,7 +107,7 @@ static int sample_to_host(uint64_t* output, size_t len, double sigma, uint64_t s
     d_cdf.upload(table);
     d_key.upload(key_words(expand_seed64(seed)));
     GaussianJob job{d_out.ptr, d_key.ptr, index, 1, domain, len, 1, 0};
-    launch_gaussian(job, d_cdf.ptr, static_cast<uint32_t>(table.size()), nullptr);
+    launch_gaussian(job, d_cdf.ptr, gaussian_scan_entries(table), nullptr);
     LSR_HIP(hipMemcpy(output, d_out.ptr, len * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
