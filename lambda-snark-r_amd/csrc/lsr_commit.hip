@@ -707,7 +707,8 @@ static void mlwe_matvec_mixed(const LweContext& c, const uint64_t* d_r, const ui
     // strided units that follow one middle unit in the block order.  The period (ratio + 1) must stay odd: blocks are dealt to the
     // XCDs and their CUs round-robin, and with an even period the middle-stage workgroups pile up on a fraction of the CUs
     // (profiles/r02_mixed_launch.txt: ratio 3 -> 5.5 ms, ratio 2 -> 3.07 ms per 1024 vectors)
-    const int ratio = env_int("LAMBDA_SNARK_COMMIT_MIX_RATIO", 4, 1, 64);
+    // default (0): in proportion to the launch's work, rounded and bumped to the next even number (rank 4: 3 -> 4, rank 2: 2)
+    const int ratio_env = env_int("LAMBDA_SNARK_COMMIT_MIX_RATIO", 0, 0, 64);
     // LAMBDA_SNARK_COMMIT_MIX_SPLIT=88: the roles of the 8 + 8 split (mlwe_mixed88) instead of the 4 + 12 split's
     const bool split88 = c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_MIX_SPLIT", 412, 0, 412) == 88;
     const int fgroups = split88 ? 1 : env_int("LAMBDA_SNARK_COMMIT_MIX_FGROUPS", 2, 1, 2);
@@ -745,7 +746,12 @@ static void mlwe_matvec_mixed(const LweContext& c, const uint64_t* d_r, const ui
             if (!job.units_m && !units_s) continue;
             any = true;
             if (job.units_m && units_s) {
-                job.s_per_m = (uint32_t)ratio;
+                uint32_t ratio = (uint32_t)ratio_env;
+                if (!ratio) {
+                    ratio = std::max<uint32_t>(1u, (units_s + job.units_m / 2) / job.units_m);
+                    ratio += ratio & 1u;                      // odd period
+                }
+                job.s_per_m = ratio;
                 job.periods = std::min(job.units_m, units_s / job.s_per_m);
             }
             hipStream_t st = lane == 0 ? s : c.side[lane - 1];
