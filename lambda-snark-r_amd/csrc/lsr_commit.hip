@@ -274,6 +274,10 @@ struct LweContext {
     mutable hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
     mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
     mutable int n_side = 0;
+    // small commitment batches (a single legacy lwe_commit above all): stream keys and messages go up in ONE copy from page-locked memory
+    static constexpr size_t kSmallInWords = 8192 + 256;
+    mutable uint64_t* host_in = nullptr;              // page-locked, kSmallInWords
+    mutable lsr::DeviceBuffer<uint64_t> ws_in;        // its device twin: [keys 4 b | messages b x msg_len]
     // two-lane pipeline of the 8 + 8 split: rings of events that order chunk c's outer passes and middle stage across the lanes
     static constexpr int kRing = 4;
     mutable hipEvent_t ev_outer[kRing] = {nullptr, nullptr, nullptr, nullptr}, ev_middle[kRing] = {nullptr, nullptr, nullptr, nullptr};
@@ -456,6 +460,13 @@ static void destroy_lwe_context(LweContext* c) {
             if (c->ev_middle[i]) (void)hipEventDestroy(c->ev_middle[i]);
         }
         if (c->host_stage) (void)hipHostFree(c->host_stage);
+        if (c->host_in) {
+            volatile uint64_t* hi = c->host_in;
+            for (size_t i = 0; i < LweContext::kSmallInWords; ++i) hi[i] = 0;
+            (void)hipHostFree(c->host_in);
+        }
+        if (c->ws_in.ptr) (void)hipMemset(c->ws_in.ptr, 0, c->ws_in.count * 8);
+        c->ws_in.release();
     } catch (...) {
     }
     destroy_ntt_context(c->ntt);
@@ -928,18 +939,33 @@ static void commit_compute(const LweContext& c, const uint64_t* messages, size_t
         const StreamKey key = seeds && seeds[j] ? derive_commit_key(seeds[j], c.keys.id, messages + j * msg_len, copy, c.t) : fresh_key();
         key_words(key, key_host.data() + 4 * j);
     }
-    LSR_HIP(hipMemcpyAsync(c.ws_keys.ptr, key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
     // only the first `copy` slots of each message matter; rows keep their msg_len pitch
     DeviceBuffer<uint64_t> big_msgs;
     uint64_t* d_msgs = c.ws_dm.ptr;
-    if (batch * msg_len > c.ws_dm.count) {
-        big_msgs.allocate(batch * msg_len);
-        d_msgs = big_msgs.ptr;
+    const uint64_t* d_keys = c.ws_keys.ptr;
+    const size_t in_words = batch * 4 + (copy ? batch * msg_len : 0);
+    if (in_words <= LweContext::kSmallInWords) {
+        // one upload from page-locked memory instead of two staged ones (every caller synchronises the stream before it returns, so
+        // the staging area is free again by the next call)
+        if (!c.host_in) {
+            LSR_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host_in), LweContext::kSmallInWords * 8, hipHostMallocDefault));
+            c.ws_in.allocate(LweContext::kSmallInWords);
+        }
+        std::memcpy(c.host_in, key_host.data(), batch * 32);
+        if (copy) std::memcpy(c.host_in + batch * 4, messages, batch * msg_len * 8);
+        LSR_HIP(hipMemcpyAsync(c.ws_in.ptr, c.host_in, in_words * 8, hipMemcpyHostToDevice, s));
+        d_keys = c.ws_in.ptr;
+        d_msgs = c.ws_in.ptr + batch * 4;
+    } else {
+        LSR_HIP(hipMemcpyAsync(c.ws_keys.ptr, key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
+        if (batch * msg_len > c.ws_dm.count) {
+            big_msgs.allocate(batch * msg_len);
+            d_msgs = big_msgs.ptr;
+        }
+        if (copy) LSR_HIP(hipMemcpyAsync(d_msgs, messages, batch * msg_len * 8, hipMemcpyHostToDevice, s));
     }
-    if (copy) LSR_HIP(hipMemcpyAsync(d_msgs, messages, batch * msg_len * 8, hipMemcpyHostToDevice, s));
-    launch_gaussian(GaussianJob{c.ws_r.ptr, c.ws_keys.ptr, 0, k, kDomR, n, batch * k, c.q}, c.cdf.ptr, c.cdf_entries, s);
-    launch_gaussian(GaussianJob{c.ws_e1.ptr, c.ws_keys.ptr, 0, k, kDomE1, n, batch * k, c.q}, c.cdf.ptr, c.cdf_entries, s);
-    launch_gaussian(GaussianJob{c.ws_e2.ptr, c.ws_keys.ptr, 0, 1, kDomE2, n, batch, c.q}, c.cdf.ptr, c.cdf_entries, s);
+    launch_gaussian3(GaussianJob{c.ws_r.ptr, d_keys, 0, k, kDomR, n, batch * k, c.q}, GaussianJob{c.ws_e1.ptr, d_keys, 0, k, kDomE1, n, batch * k, c.q},
+                     GaussianJob{c.ws_e2.ptr, d_keys, 0, 1, kDomE2, n, batch, c.q}, c.cdf.ptr, c.cdf_entries, s);
     mlwe_matvec_device(c, c.ws_r.ptr, c.ws_e1.ptr, c.ws_u.ptr, batch, s);    // leaves r_hat in ws_r
     // v = INTT(<b_hat, r_hat>) + e2 + Delta m
     matvec(c, c.ws_v.ptr, c.b_hat.ptr, c.ws_r.ptr, nullptr, 1, k, 0, 1, batch, s);

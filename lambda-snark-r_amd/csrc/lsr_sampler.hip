@@ -15,7 +15,7 @@ namespace lsr {
 constexpr int kSamplerThreads = 256;
 
 // One lane = one ChaCha block = eight samples.  The CDT table sits in LDS at 63-bit precision (lsr_sampler.hpp).
-__global__ void __launch_bounds__(kSamplerThreads) gaussian_kernel(GaussianJob job, const uint64_t* __restrict__ cdf_global, uint32_t entries) {
+__device__ __forceinline__ void gaussian_body(const GaussianJob& job, const uint64_t* __restrict__ cdf_global, uint32_t entries) {
     extern __shared__ uint64_t cdf[];
     for (uint32_t i = threadIdx.x; i < entries; i += kSamplerThreads) cdf[i] = cdf_global[i] >> 1;
     __syncthreads();
@@ -44,6 +44,15 @@ __global__ void __launch_bounds__(kSamplerThreads) gaussian_kernel(GaussianJob j
         if ((uint64_t)s >= left) break;
         dst[s] = gaussian_value(magnitude[s], w[s], job.q);
     }
+}
+__global__ void __launch_bounds__(kSamplerThreads) gaussian_kernel(GaussianJob job, const uint64_t* __restrict__ cdf_global, uint32_t entries) {
+    gaussian_body(job, cdf_global, entries);
+}
+// three jobs in one launch (blockIdx.y picks the job; the grid is as wide as the widest): r, e1 and e2 of a commitment batch —
+// a single legacy lwe_commit call is launch-bound, and these are three of its nine kernels
+__global__ void __launch_bounds__(kSamplerThreads) gaussian3_kernel(GaussianJob a, GaussianJob b, GaussianJob c, const uint64_t* __restrict__ cdf_global,
+                                                                     uint32_t entries) {
+    gaussian_body(blockIdx.y == 0 ? a : (blockIdx.y == 1 ? b : c), cdf_global, entries);
 }
 
 // One lane = one ChaCha block = eight uniform residues.
@@ -84,6 +93,18 @@ void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t ent
     if (job.objects > 0xFFFFFFFFull || job.components == 0) throw std::runtime_error("gaussian job: objects must fit 32 bits, components >= 1");
     const unsigned grid = static_cast<unsigned>((lanes + kSamplerThreads - 1) / kSamplerThreads);
     hipLaunchKernelGGL(gaussian_kernel, dim3(grid), dim3(kSamplerThreads), entries * sizeof(uint64_t), stream, job, d_cdf, entries);
+    LSR_HIP(hipGetLastError());
+}
+
+void launch_gaussian3(const GaussianJob& a, const GaussianJob& b, const GaussianJob& c, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream) {
+    uint64_t widest = 0;
+    for (const GaussianJob* j : {&a, &b, &c}) {
+        if (j->objects > 0xFFFFFFFFull || j->components == 0) throw std::runtime_error("gaussian job: objects must fit 32 bits, components >= 1");
+        widest = std::max<uint64_t>(widest, ((j->samples + kSamplesPerBlock - 1) / kSamplesPerBlock) * j->objects);
+    }
+    if (!widest) return;
+    const unsigned grid = static_cast<unsigned>((widest + kSamplerThreads - 1) / kSamplerThreads);
+    hipLaunchKernelGGL(gaussian3_kernel, dim3(grid, 3), dim3(kSamplerThreads), entries * sizeof(uint64_t), stream, a, b, c, d_cdf, entries);
     LSR_HIP(hipGetLastError());
 }
 

@@ -98,6 +98,8 @@ struct BlindSampler {
 };
 
 void launch_gaussian(const GaussianJob& job, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream);
+// three independent jobs in one launch (same table)
+void launch_gaussian3(const GaussianJob& a, const GaussianJob& b, const GaussianJob& c, const uint64_t* d_cdf, uint32_t entries, hipStream_t stream);
 // out[o][i] = floor(word_i * q / 2^64), object o = (keys[4 (o / components) ..], domain, index_base + o % components)
 void launch_uniform(uint64_t* out, const uint64_t* d_keys, uint64_t index_base, uint32_t components, uint32_t domain,
                     uint64_t samples, uint64_t objects, uint64_t q, hipStream_t stream);
