@@ -205,12 +205,15 @@ __device__ __forceinline__ uint64_t div128_by_q(uint64_t hi, uint64_t lo, const 
 }
 
 // flag |= OR_i ( round(t * w_i / q) mod t ) xor msg_i   — OR-of-XOR compare of commitment.cpp:223-228
+// minuend (optional, canonical residues): decode minuend_i - w_i instead of w_i
 __global__ void __launch_bounds__(256) decode_compare_kernel(const uint64_t* __restrict__ w, const uint64_t* __restrict__ msg, uint64_t msg_len,
-                                                               uint64_t t, ModParams p, unsigned long long* __restrict__ flag) {
+                                                               uint64_t t, ModParams p, unsigned long long* __restrict__ flag,
+                                                               const uint64_t* __restrict__ minuend = nullptr) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint64_t diff = 0;
     if (i < msg_len) {
-        const uint64_t lo0 = w[i] * t, hi0 = __umul64hi(w[i], t);
+        const uint64_t wi = minuend ? (minuend[i] >= w[i] ? minuend[i] - w[i] : minuend[i] + p.q - w[i]) : w[i];
+        const uint64_t lo0 = wi * t, hi0 = __umul64hi(wi, t);
         const uint64_t lo = lo0 + (p.q >> 1);
         const uint64_t hi = hi0 + (lo < lo0);
         const uint64_t decoded = div128_by_q(hi, lo, p) % t;
@@ -278,6 +281,7 @@ struct LweContext {
     static constexpr size_t kSmallInWords = 8192 + 256;
     mutable uint64_t* host_in = nullptr;              // page-locked, kSmallInWords
     mutable lsr::DeviceBuffer<uint64_t> ws_in;        // its device twin: [keys 4 b | messages b x msg_len]
+    mutable lsr::DeviceBuffer<uint64_t> ws_body;      // lwe_verify_opening: the body u || v of one commitment
     // two-lane pipeline of the 8 + 8 split: rings of events that order chunk c's outer passes and middle stage across the lanes
     static constexpr int kRing = 4;
     mutable hipEvent_t ev_outer[kRing] = {nullptr, nullptr, nullptr, nullptr}, ev_middle[kRing] = {nullptr, nullptr, nullptr, nullptr};
@@ -467,6 +471,7 @@ static void destroy_lwe_context(LweContext* c) {
         }
         if (c->ws_in.ptr) (void)hipMemset(c->ws_in.ptr, 0, c->ws_in.count * 8);
         c->ws_in.release();
+        c->ws_body.release();
     } catch (...) {
     }
     destroy_ntt_context(c->ntt);
@@ -1107,18 +1112,17 @@ static int verify_opening(const LweContext& c, const LweCommitment* cm, const ui
     std::lock_guard<std::mutex> lock(c.mutex);
     ensure_workspace(c, 1);
     hipStream_t s = work_stream(*c.ntt);
-    LSR_HIP(hipMemcpyAsync(c.ws_u.ptr, body, kn * 8, hipMemcpyHostToDevice, s));
-    LSR_HIP(hipMemcpyAsync(c.ws_v.ptr, body + kn, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    // a single call is launch-bound: the body u || v goes up in one copy, v stays in the coefficient domain (by linearity
+    // v - INTT(<s_hat, NTT(u)>) is what the reference decodes) and the subtraction rides in the decode kernel — four kernels, not six
+    if (c.ws_body.count < kn + n) c.ws_body.allocate(kn + n);
+    LSR_HIP(hipMemcpyAsync(c.ws_body.ptr, body, (kn + n) * 8, hipMemcpyHostToDevice, s));
     LSR_HIP(hipMemcpyAsync(c.ws_dm.ptr, message, msg_len * 8, hipMemcpyHostToDevice, s));
     LSR_HIP(hipMemsetAsync(c.ws_flag.ptr, 0, sizeof(unsigned long long), s));
-    launch_ntt(*c.ntt, c.ws_u.ptr, k, false, s);
-    launch_ntt(*c.ntt, c.ws_v.ptr, 1, false, s);
-    // e2 <- <s_hat, u_hat>;  e2 <- v_hat - e2;  INTT
-    matvec(c, c.ws_e2.ptr, c.s_hat.ptr, c.ws_u.ptr, nullptr, 1, k, 0, 1, 1, s);
-    hipLaunchKernelGGL(rsub_mod_kernel, dim3(grid_for(n)), dim3(256), 0, s, c.ws_e2.ptr, c.ws_v.ptr, (uint64_t)n, c.q);
+    launch_ntt(*c.ntt, c.ws_body.ptr, k, false, s);
+    matvec(c, c.ws_e2.ptr, c.s_hat.ptr, c.ws_body.ptr, nullptr, 1, k, 0, 1, 1, s);      // <s_hat, u_hat>
     launch_ntt(*c.ntt, c.ws_e2.ptr, 1, true, s);
     hipLaunchKernelGGL(decode_compare_kernel, dim3((unsigned)((msg_len + 255) / 256)), dim3(256), 0, s, c.ws_e2.ptr, c.ws_dm.ptr, (uint64_t)msg_len, c.t,
-                       c.ntt->mod, c.ws_flag.ptr);
+                       c.ntt->mod, c.ws_flag.ptr, c.ws_body.ptr + kn);
     LSR_HIP(hipGetLastError());
     unsigned long long flag = 1;
     LSR_HIP(hipMemcpyAsync(&flag, c.ws_flag.ptr, sizeof flag, hipMemcpyDeviceToHost, s));
