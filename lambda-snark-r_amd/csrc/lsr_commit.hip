@@ -754,7 +754,7 @@ static void mlwe_matvec_mixed(const LweContext& c, const uint64_t* d_r, const ui
             }
             if (t >= 1 && valid(t - 1)) {
                 job.i_data = d_u + first_of(t - 1) * vec_words;
-                job.i_add = d_e1 ? d_e1 + first_of(t - 1) * vec_words : nullptr;
+                job.i_add = d_e1 + first_of(t - 1) * vec_words;
                 job.i_polys = (uint32_t)(count_of(t - 1) * k);
                 job.units_i = job.i_polys;
             }
@@ -800,7 +800,7 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
     // ties with the default 4 + 12 split (3.22-3.31 ms per 1024 rank-4 vectors either way); LAMBDA_SNARK_COMMIT_TWO_LANE=1 adds
     // the two-lane schedule, which is slower today because the outer passes crawl at one workgroup per CU.
     // default for n = 2^16 with the blinding residues given: mixed launches (one kernel, three roles; see mlwe_matvec_mixed)
-    if (c.logn == 16 && !d_keys && env_int("LAMBDA_SNARK_COMMIT_MIXED", 1, 0, 1) && !env_int("LAMBDA_SNARK_COMMIT_TWO_LANE", 0, 0, 1) &&
+    if (c.logn == 16 && d_e1 && !d_keys && env_int("LAMBDA_SNARK_COMMIT_MIXED", 1, 0, 1) && !env_int("LAMBDA_SNARK_COMMIT_TWO_LANE", 0, 0, 1) &&
         env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) != 88) {
         mlwe_matvec_mixed(c, d_r, d_e1, d_u, batch, s);
         return;

@@ -435,7 +435,7 @@ __device__ __forceinline__ void mixed_forward_round(uint64_t* __restrict__ dst, 
 struct MixedJob {
     const uint64_t* m_ws; uint64_t* m_out; uint32_t m_vectors;        // middle stage: workspace -> u (raw), m_vectors witness vectors
     uint64_t* f_dst; const uint64_t* f_src; uint32_t f_polys;         // forward round: caller's r -> workspace (raw), f_polys polynomials
-    uint64_t* i_data; const uint64_t* i_add; uint32_t i_polys;        // inverse round in place on u (+ i_add, canonical), i_polys polynomials
+    uint64_t* i_data; const uint64_t* i_add; uint32_t i_polys;        // inverse round in place on u + i_add (canonical, never NULL), i_polys polynomials
     uint32_t units_m, units_f, units_i;                               // units of 8 workgroups per role
     uint32_t s_per_m, periods;                                        // interleaved part: periods x (1 middle unit + s_per_m strided units)
     uint32_t f_groups;                                                // 256-lane groups per half workgroup in the forward role: 1 or 2
@@ -477,12 +477,10 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mixed(MixedJob job, const 
     if (forward) {
         if (job.f_groups == 2) mixed_forward_round<2>(job.f_dst, job.f_src, (size_t)job.f_polys << p.logn, lo, p, fwd_tw, vblock * 2u, vthread);
         else mixed_forward_round<1>(job.f_dst, job.f_src, (size_t)job.f_polys << p.logn, lo, p, fwd_tw, vblock, vthread);
-    } else if (job.i_add != nullptr)
+    } else {
         strided_round_body<ArithF64, 4, true, true, false, true, 0>(job.i_data, (size_t)job.i_polys << p.logn, lo, p, inv_tw, cs, job.i_add, BlindSampler{},
                                                                     vblock, vthread);
-    else
-        strided_round_body<ArithF64, 4, true, true, false, false, 0>(job.i_data, (size_t)job.i_polys << p.logn, lo, p, inv_tw, cs, nullptr, BlindSampler{},
-                                                                     vblock, vthread);
+    }
 }
 
 
