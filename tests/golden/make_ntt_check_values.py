@@ -26,7 +26,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 MASK = (1 << 64) - 1
 SEED = 0xDEADBEEF
-CASES = [(12289, 256), (17592169062401, 4096), (17592182243329, 65536)]
+CASES = [(12289, 256), (17592169062401, 4096), (17592182243329, 65536),
+         # further sizes (round 2): the first two-pass degree, the 5-bit strided round, a 60-bit modulus (u64 flavour)
+         (17592186028033, 8192), (17592180539393, 131072), (1152921504606830593, 1024)]
+# moduli that are "the largest `bits`-bit prime = 1 (mod 2n)" (what SEAL's prime generator returns): re-derived below
+LARGEST_PRIME_CASES = {17592182243329: (44, 65536), 17592186028033: (44, 8192), 17592180539393: (44, 131072), 1152921504606830593: (60, 1024)}
 # rust-api/lambda-snark/src/r1cs.rs:534-547 (data of the reference, restated)
 ROOTS_Q = 17592169062401
 ROOTS_TABLE = [[4, 981206394875], [8, 4268641988953], [16, 9400386778549], [32, 15690227524213], [64, 8332322609789],
@@ -55,6 +59,40 @@ def prime_factors(m):
     if m > 1:
         out.append(m)
     return out
+
+
+def is_prime(m):
+    """Deterministic Miller-Rabin for m < 3.3 * 10^24 (the first 13 primes as bases)."""
+    if m < 2:
+        return False
+    small = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41)
+    for p in small:
+        if m % p == 0:
+            return m == p
+    d, r = m - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in small:
+        x = pow(a, d, m)
+        if x in (1, m - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % m
+            if x == m - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def largest_prime_1_mod(bits, modulus):
+    """Largest prime below 2^bits that is 1 modulo `modulus`."""
+    c = (1 << bits) - 1
+    c -= (c - 1) % modulus
+    while not is_prime(c):
+        c -= modulus
+    return c
 
 
 def minimal_primitive_2n_root(q, n):
@@ -97,7 +135,10 @@ def evaluate_all(a, psi, q):
 
 def build():
     cases = []
+    for q, (pbits, pn) in LARGEST_PRIME_CASES.items():
+        assert largest_prime_1_mod(pbits, 2 * pn) == q, (q, pbits, pn)
     for q, n in CASES:
+        assert is_prime(q) and (q - 1) % (2 * n) == 0, (q, n)
         bits = n.bit_length() - 1
         a = [z % q for z in splitmix_stream(SEED, n)]
         psi = minimal_primitive_2n_root(q, n)

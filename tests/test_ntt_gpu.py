@@ -213,6 +213,43 @@ def test_config2_full_size_properties(pkg, oracle):
     ctx.close()
 
 
+def test_gpu_reproduces_the_independent_check_values(pkg, lib, golden_dir):
+    """tests/golden/ntt_check_values.json (written by the pure-Python generator next to it: minimal-psi search, even/odd
+    evaluation of the defining formula — no oracle, no library) against the GPU directly: psi, the first outputs and the
+    SHA-256 of the whole forward transform of a[i] = splitmix64_i(0xDEADBEEF) mod q, for every case in the file (n = 256 ... 2^17,
+    44- and 60-bit moduli, both arithmetic flavours where the modulus allows), through the legacy host-pointer ABI."""
+    import hashlib, json, os
+    with open(os.path.join(golden_dir, "ntt_check_values.json")) as f:
+        golden = json.load(f)
+    mask = (1 << 64) - 1
+
+    def splitmix(seed, count):
+        x, out = seed, []
+        for _ in range(count):
+            x = (x + 0x9E3779B97F4A7C15) & mask
+            z = x
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+            out.append(z ^ (z >> 31))
+        return out
+
+    for case in golden["cases"]:
+        q, n = case["q"], case["n"]
+        a = np.array([z % q for z in splitmix(golden["splitmix_seed"], n)], dtype=np.uint64)
+        assert [int(x) for x in a[:3]] == case["a"]
+        for mode in ((0, 1) if q < 2**45 else (1,)):          # FP64-FMA flavour and SEAL's u64 Harvey/Shoup butterflies
+            lib.lsr_set_arith_mode(mode)
+            ctx = pkg.NttContext(q, n)
+            lib.lsr_set_arith_mode(0)
+            x = a.copy()
+            assert lib.ntt_forward(ctx.handle, x.ctypes.data, n) == 0
+            assert [int(v) for v in x[:3]] == case["ntt"], (q, n, mode)
+            assert hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest() == case["sha256"], (q, n, mode)
+            assert lib.ntt_inverse(ctx.handle, x.ctypes.data, n) == 0
+            assert np.array_equal(x, a)
+            ctx.close()
+
+
 @pytest.mark.parametrize("n", [4096, 65536, 131072])
 def test_f64_flavour_at_its_modulus_bound(pkg, oracle, n):
     """the FP64-FMA Barrett arithmetic is exact for q < 2^45.  Largest 45-bit primes = 1 (mod 2n),
