@@ -212,23 +212,32 @@ __device__ __forceinline__ void tile_forward_body(uint64_t* __restrict__ data, s
         } else {
             static_assert(std::is_same_v<A, ArithGold> && !RAW_IN, "fused elementwise work: first pass of a Goldilocks transform");
             const rsrc_t r1 = make_rsrc(fuse.x1 + tile_base, tile_bytes);
-            uint64_t o1[kRegs];
-#pragma unroll
-            for (int k = 0; k < kRegs; ++k) o1[k] = buf_load64(r1, base * 8u, reg_offset<LO, R>(k) * 8u);
             if constexpr (MODE == 1) {
+                uint64_t o1[kRegs];
+#pragma unroll
+                for (int k = 0; k < kRegs; ++k) o1[k] = buf_load64(r1, base * 8u, reg_offset<LO, R>(k) * 8u);
 #pragma unroll
                 for (int k = 0; k < kRegs; ++k) v[k] = gold_mul(A::load(raw[k], p), A::load(o1[k], p));
             } else {
+                // a and b come in two halves: three operand sets live at once cost 138 VGPRs and a wave of occupancy
                 const rsrc_t r2 = make_rsrc(fuse.x2 + tile_base, tile_bytes);
-                uint64_t o2[kRegs];
 #pragma unroll
-                for (int k = 0; k < kRegs; ++k) o2[k] = buf_load64(r2, base * 8u, reg_offset<LO, R>(k) * 8u);
+                for (int k = 0; k < kRegs; ++k) v[k] = A::load(raw[k], p);
 #pragma unroll
-                for (int k = 0; k < kRegs; ++k) {
-                    v[k] = A::load(raw[k], p);
-                    const uint32_t at = base + reg_offset<LO, R>(k);                    // index within the tile
-                    if (at * 8u < tile_bytes && gold_mul(A::load(o1[k], p), A::load(o2[k], p)) != v[k])
-                        atomicOr(&fuse.bad[(tile_base + at) >> p.logn], 1u);             // only ever taken for an unsatisfied instance
+                for (int half = 0; half < 2; ++half) {
+                    constexpr int H = kRegs / 2;
+                    uint64_t o1[H], o2[H];
+#pragma unroll
+                    for (int k = 0; k < H; ++k) {
+                        o1[k] = buf_load64(r1, base * 8u, reg_offset<LO, R>(half * H + k) * 8u);
+                        o2[k] = buf_load64(r2, base * 8u, reg_offset<LO, R>(half * H + k) * 8u);
+                    }
+#pragma unroll
+                    for (int k = 0; k < H; ++k) {
+                        const uint32_t at = base + reg_offset<LO, R>(half * H + k);     // index within the tile
+                        if (at * 8u < tile_bytes && gold_mul(A::load(o1[k], p), A::load(o2[k], p)) != v[half * H + k])
+                            atomicOr(&fuse.bad[(tile_base + at) >> p.logn], 1u);         // only ever taken for an unsatisfied instance
+                    }
                 }
             }
         }
