@@ -812,7 +812,9 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
     const uint32_t k = c.k;
     const size_t vec_words = (size_t)k << c.logn;
     const int want = env_int("LAMBDA_SNARK_COMMIT_STREAMS", 2, 1, LweContext::kMaxSide);
-    const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_CHUNK_MIB", 128, 1, 4096);
+    // default chunk: 128 MiB with the blinding residues given, 64 MiB when they are sampled on the way (3.60 -> 3.52 ms per 1024
+    // rank-4 vectors; profiles/r02_mixed_launch.txt item 13)
+    const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_CHUNK_MIB", (!d_e1 && d_keys) ? 64 : 128, 1, 4096);
     const size_t chunk = std::max<size_t>(1, (chunk_mib << 20) / (vec_words * 8));
     const int streams = static_cast<int>(std::min<size_t>((size_t)want, (batch + chunk - 1) / chunk));
     // lane 0 is the caller's stream itself, lanes 1.. are side streams: every stream a process opens competes for the runtime's few
