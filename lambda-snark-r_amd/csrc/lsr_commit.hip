@@ -269,25 +269,24 @@ struct LweContext {
     // pinned host staging for the gather of a batch (two bulk D2H copies instead of two per commitment)
     mutable uint64_t* host_stage = nullptr;
     mutable size_t host_stage_words = 0;
-    // fused matrix–vector pipeline (lsr_commit_fused.hpp): lane-major copy of A_hat, per-stream chunk workspaces, side streams
-    static constexpr int kMaxSide = 4;
+    // fused matrix–vector pipeline (lsr_commit_fused.hpp): lane-major copy of A_hat, per-lane chunk workspaces, side streams
+    static constexpr int kMaxSide = 2;
     lsr::DeviceBuffer<double> a_perm;
-    lsr::DeviceBuffer<double> a_perm8;     // layout of the 8 + 8 pipeline (n = 2^16 only)
     mutable lsr::DeviceBuffer<uint64_t> ws_mid, ws_e1_slots;
-    mutable hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
-    mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr, nullptr};
+    mutable hipStream_t side[kMaxSide] = {nullptr, nullptr};
+    mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr};
     mutable int n_side = 0;
+    // pipeline selection, read from the environment ONCE when the context is created (include/lambda_snark/batch.h lists the
+    // variables): a context never changes the kernels that sign its commitments under the caller's feet
+    struct Tuning {
+        bool fused = true;     // LAMBDA_SNARK_COMMIT_FUSED=0: the unfused round-1 kernels (A/B runs and tests)
+        bool mixed = true;     // LAMBDA_SNARK_COMMIT_MIXED=0: three launches per chunk instead of one mixed launch (n = 2^16, e1 given)
+    } tuning;
     // small commitment batches (a single legacy lwe_commit above all): stream keys and messages go up in ONE copy from page-locked memory
     static constexpr size_t kSmallInWords = 8192 + 256;
     mutable uint64_t* host_in = nullptr;              // page-locked, kSmallInWords
     mutable lsr::DeviceBuffer<uint64_t> ws_in;        // its device twin: [keys 4 b | messages b x msg_len]
     mutable lsr::DeviceBuffer<uint64_t> ws_body;      // lwe_verify_opening: the body u || v of one commitment
-    // two-lane pipeline of the 8 + 8 split: rings of events that order chunk c's outer passes and middle stage across the lanes
-    static constexpr int kRing = 4;
-    mutable hipEvent_t ev_outer[kRing] = {nullptr, nullptr, nullptr, nullptr}, ev_middle[kRing] = {nullptr, nullptr, nullptr, nullptr};
-    // the two lanes' own streams: [0] outer passes, [1] middle stages; with lane_outer_cus > 0 they carry complementary CU masks
-    mutable hipStream_t lane[2] = {nullptr, nullptr};
-    mutable int lane_outer_cus = -1;
 };
 
 namespace lsr {
@@ -346,13 +345,19 @@ static void ensure_workspace(const LweContext& c, size_t batch) {
     c.ws_v.allocate(batch * c.n);
     c.ws_dm.allocate(batch * c.n);   // message slots of a batch (at most n per commitment); verify's message buffer
     c.ws_keys.allocate(batch * 4);
+    LSR_HIP(hipMemset(c.ws_keys.ptr, 0xA5, batch * 32));   // never a valid stale key: a use before the upload shows up in the parity tests
     if (!c.ws_flag.ptr) c.ws_flag.allocate(1);
     c.ws_batch = batch;
 }
 
 // the fused pipeline exists for the FP64 flavour, two-pass degrees whose low pass is a full 4096-residue tile, ranks <= 4
 static bool fused_eligible(const LweContext& c) {
-    return c.ntt->use_f64 && (c.logn == 16 || c.logn == 17) && c.k >= 1 && c.k <= 4;
+    return c.tuning.fused && c.ntt->use_f64 && (c.logn == 16 || c.logn == 17) && c.k >= 1 && c.k <= 4;
+}
+
+static bool env_flag(const char* name, bool fallback) {
+    const char* e = std::getenv(name);
+    return (e && (e[0] == '0' || e[0] == '1') && e[1] == 0) ? e[0] == '1' : fallback;
 }
 
 static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_seed, int device, const ContextKeys* replicate = nullptr) {
@@ -372,6 +377,8 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
         return nullptr;
     }
     std::unique_ptr<LweContext> c(new LweContext);
+    c->tuning.fused = env_flag("LAMBDA_SNARK_COMMIT_FUSED", true);
+    c->tuning.mixed = env_flag("LAMBDA_SNARK_COMMIT_MIXED", true);
     c->params = *params;
     c->q = q; c->t = t; c->delta = q / t; c->n = n; c->k = k; c->sigma = params->sigma;
     // Noise budget: opening decodes round(t/q (Delta m + <e,r> - <s,e1> + e2)); the noise term is a sum of 2 k n products of
@@ -417,11 +424,6 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
             c->a_perm.allocate((size_t)k * kn);
             hipLaunchKernelGGL(f8_permute_matrix_kernel, dim3(grid_for((uint64_t)k * kn)), dim3(256), 0, s, c->a_perm.ptr, c->a_hat.ptr, k, c->logn);
             LSR_HIP(hipGetLastError());
-            if (c->logn == 16) {
-                c->a_perm8.allocate((size_t)k * kn);
-                hipLaunchKernelGGL(m8_permute_matrix_kernel, dim3(grid_for((uint64_t)k * kn)), dim3(256), 0, s, c->a_perm8.ptr, c->a_hat.ptr, k, c->logn);
-                LSR_HIP(hipGetLastError());
-            }
         }
         LSR_HIP(hipStreamSynchronize(s));
         LSR_HIP(hipMemset(sec_key.ptr, 0, 32));
@@ -449,7 +451,7 @@ static void destroy_lwe_context(LweContext* c) {
         c->a_hat.release(); c->s_hat.release(); c->b_hat.release(); c->cdf.release();
         c->ws_r.release(); c->ws_e1.release(); c->ws_e2.release(); c->ws_u.release(); c->ws_v.release();
         c->ws_dm.release(); c->ws_keys.release(); c->ws_flag.release();
-        c->a_perm.release(); c->a_perm8.release(); c->ws_mid.release();
+        c->a_perm.release(); c->ws_mid.release();
         if (c->ws_e1_slots.ptr) (void)hipMemset(c->ws_e1_slots.ptr, 0, c->ws_e1_slots.count * 8);
         c->ws_e1_slots.release();
         for (int i = 0; i < c->n_side; ++i) {
@@ -457,12 +459,6 @@ static void destroy_lwe_context(LweContext* c) {
             if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         }
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-        for (int i = 0; i < 2; ++i)
-            if (c->lane[i]) (void)hipStreamDestroy(c->lane[i]);
-        for (int i = 0; i < LweContext::kRing; ++i) {
-            if (c->ev_outer[i]) (void)hipEventDestroy(c->ev_outer[i]);
-            if (c->ev_middle[i]) (void)hipEventDestroy(c->ev_middle[i]);
-        }
         if (c->host_stage) (void)hipHostFree(c->host_stage);
         if (c->host_in) {
             volatile uint64_t* hi = c->host_in;
@@ -478,256 +474,71 @@ static void destroy_lwe_context(LweContext* c) {
     delete c;
 }
 
-static int env_int(const char* name, int fallback, int lo, int hi) {
-    if (const char* e = std::getenv(name)) {
-        const long v = std::atol(e);
-        if (v >= lo && v <= hi) return static_cast<int>(v);
-    }
-    return fallback;
-}
+// Build-time constants of the chunk schedules (round 2 measured the alternatives: profiles/r02_mixed_launch.txt,
+// r02_fused_commit_stream_sweep.txt; round 3 removed the environment knobs that selected them):
+constexpr size_t kMixedChunkBytes = size_t(64) << 20;     // mixed launches: 2 lanes x 2 slots x 64 MiB stay inside the Infinity Cache
+constexpr int kMixedLanes = 2;                            // independent pipelines of mixed launches (lane 0 = the caller's stream)
+constexpr uint32_t kMixedForwardGroups = 2;               // 256-lane groups per half workgroup in the forward role
+constexpr size_t kFusedChunkBytes = size_t(128) << 20;    // three-launch schedule, blinding residues given
+constexpr size_t kSampledChunkBytes = size_t(64) << 20;   // three-launch schedule, blinding residues sampled in the strided rounds
+constexpr int kFusedStreams = 2;                          // chunk lanes of the three-launch schedule (lane 0 = the caller's stream)
 
 template <int K>
 static void launch_mid(const LweContext& c, const uint64_t* ws, uint64_t* d_u, size_t vectors, hipStream_t s) {
     const unsigned grid = static_cast<unsigned>(vectors << (c.logn - 12));
-    // experiment knob: unused dynamic LDS that lowers the kernel's residency (e.g. 16384 -> one workgroup per CU), leaving
-    // registers and wave slots for the memory-bound outer rounds of neighbouring chunks on other streams
-    const unsigned pad = static_cast<unsigned>(env_int("LAMBDA_SNARK_COMMIT_MID_LDS_PAD", 0, 0, 90000));
-    hipLaunchKernelGGL((mlwe_mid_fused8<K>), dim3(grid), dim3(kF8Threads), pad, s, ws, d_u, c.a_perm.ptr, (uint32_t)vectors, c.ntt->mod, c.ntt->fwd_f64.ptr,
+    hipLaunchKernelGGL((mlwe_mid_fused8<K>), dim3(grid), dim3(kF8Threads), 0, s, ws, d_u, c.a_perm.ptr, (uint32_t)vectors, c.ntt->mod, c.ntt->fwd_f64.ptr,
                        c.ntt->inv_f64.ptr);
     LSR_HIP(hipGetLastError());
 }
 
-template <int K>
-static void launch_mid8(const LweContext& c, const uint64_t* ws, uint64_t* d_u, size_t vectors, hipStream_t s) {
-    // 8 waves per workgroup (default): the middle stage has the CU to itself; LAMBDA_SNARK_COMMIT_MID_WAVES=4: three workgroups
-    // per CU by LDS, one wave slot per SIMD left for the outer passes of a neighbouring chunk (for the two-lane schedule)
-    if (env_int("LAMBDA_SNARK_COMMIT_MID_WAVES", 8, 4, 8) == 8) {
-        hipLaunchKernelGGL((mlwe_mid8_w8<K>), dim3(static_cast<unsigned>(vectors << 4)), dim3(512), 0, s, ws, d_u, c.a_perm8.ptr, (uint32_t)vectors,
-                           c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr);
-    } else {
-        hipLaunchKernelGGL((mlwe_mid8_w4<K>), dim3(static_cast<unsigned>(vectors << 5)), dim3(256), 0, s, ws, d_u, c.a_perm8.ptr, (uint32_t)vectors,
-                           c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr);
+// lanes 1.. of a chunk schedule (lane 0 is the caller's stream: every stream a process opens competes for the runtime's few
+// hardware queues, and two lanes that land on one queue overlap nothing — profiles/r02_commit_hw_queues.txt)
+static void ensure_side_streams(const LweContext& c, int lanes) {
+    while (c.n_side < lanes - 1) {
+        LSR_HIP(hipStreamCreateWithFlags(&c.side[c.n_side], hipStreamNonBlocking));
+        LSR_HIP(hipEventCreateWithFlags(&c.ev_join[c.n_side], hipEventDisableTiming));
+        ++c.n_side;
     }
-    LSR_HIP(hipGetLastError());
-}
-
-// TWO-LANE software pipeline of the fused commitment (LAMBDA_SNARK_COMMIT_TWO_LANE=1, either split).  Lane "outer" (one stream)
-// runs the memory-bound passes of all chunks back to back — F(0), F(1), I(0), F(2), I(1), ... — lane "middle" (another stream)
-// the FP64-bound stages M(0), M(1), ... with M(c) after F(c) and I(c) after M(c) (event rings).  The lanes own DISJOINT compute
-// units: LAMBDA_SNARK_COMMIT_OUTER_CUS = o gives the outer lane o CUs of every XCD and the middle lane the other 32 - o
-// (hipExtStreamCreateWithCUMask; mask bit = cu * 8 + xcd on this part, tools/ubench_cumask.hip), so the streaming passes and the
-// FP64 stage neither queue behind each other for wave slots nor share a register file.  o = 0: unmasked lanes (round-robin
-// placement: every kernel then takes about twice its stand-alone time, profiles/r02_commit_split_88.txt).
-// Side streams that do not share a hardware queue.  Plain streams are multiplexed onto a small pool of hardware queues (four by
-// default, the least-used one at creation) and two streams of one context can land on the same queue — their kernels then run
-// strictly one after the other and the round-robin chunk schedule overlaps nothing (seen in bench.py: every commit kernel on one
-// queue, 3.44 ms per 1024 vectors instead of 3.2).  The runtime keeps one queue pool per stream priority, so side streams of
-// alternating priority (LAMBDA_SNARK_COMMIT_STREAM_MODE=1) cannot share a queue; mode 2: streams with an all-CU mask
-// (a dedicated queue each; measured slower); mode 0, default: plain streams — the pipeline keeps its own stream count at one.
-static hipStream_t create_side_stream(int device, int ordinal) {
-    hipStream_t st = nullptr;
-    const int mode = env_int("LAMBDA_SNARK_COMMIT_STREAM_MODE", 0, 0, 2);
-    if (mode == 1) {
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
-            hipStreamCreateWithPriority(&st, hipStreamNonBlocking, (ordinal & 1) ? greatest : (least + greatest) / 2) == hipSuccess)
-            return st;
-        (void)hipGetLastError();
-    } else if (mode == 2) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
-            std::vector<uint32_t> all((prop.multiProcessorCount + 31) / 32, 0);
-            for (int cu = 0; cu < prop.multiProcessorCount; ++cu) all[cu / 32] |= 1u << (cu % 32);
-            if (hipExtStreamCreateWithCUMask(&st, (uint32_t)all.size(), all.data()) == hipSuccess) return st;
-            (void)hipGetLastError();
-        }
-    }
-    LSR_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    return st;
-}
-
-static void ensure_lanes(const LweContext& c, int outer_cus) {
-    if (c.lane[0] && c.lane_outer_cus == outer_cus) return;
-    for (int i = 0; i < 2; ++i)
-        if (c.lane[i]) { LSR_HIP(hipStreamSynchronize(c.lane[i])); LSR_HIP(hipStreamDestroy(c.lane[i])); c.lane[i] = nullptr; }
-    if (outer_cus <= 0) {
-        for (int i = 0; i < 2; ++i) c.lane[i] = create_side_stream(c.ntt->device, i);
-    } else {
-        hipDeviceProp_t prop;
-        LSR_HIP(hipGetDeviceProperties(&prop, c.ntt->device));
-        constexpr int kXcds = 8;                                       // gfx950: 8 XCDs
-        const int per_xcd = prop.multiProcessorCount / kXcds;
-        const int o = std::min(outer_cus, per_xcd - 1);
-        const int words = (prop.multiProcessorCount + 31) / 32;
-        std::vector<uint32_t> outer_mask(words, 0), middle_mask(words, 0);
-        for (int cu = 0; cu < per_xcd; ++cu)
-            for (int x = 0; x < kXcds; ++x) {
-                const int bit = cu * kXcds + x;
-                (cu < o ? outer_mask : middle_mask)[bit / 32] |= 1u << (bit % 32);
-            }
-        LSR_HIP(hipExtStreamCreateWithCUMask(&c.lane[0], (uint32_t)words, outer_mask.data()));
-        LSR_HIP(hipExtStreamCreateWithCUMask(&c.lane[1], (uint32_t)words, middle_mask.data()));
-    }
-    c.lane_outer_cus = outer_cus;
-}
-
-static void mlwe_matvec_two_lane(const LweContext& c, const uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s,
-                                 const uint64_t* d_keys, bool split88) {
-    const uint32_t k = c.k;
-    const size_t vec_words = (size_t)k << c.logn;
-    const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_CHUNK_MIB", 128, 1, 4096);
-    const size_t chunk = std::max<size_t>(1, (chunk_mib << 20) / (vec_words * 8));
-    const size_t chunks = (batch + chunk - 1) / chunk;
-    ensure_lanes(c, env_int("LAMBDA_SNARK_COMMIT_OUTER_CUS", 0, 0, 31));
     if (!c.ev_fork) LSR_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < LweContext::kRing; ++i) {
-        if (!c.ev_outer[i]) LSR_HIP(hipEventCreateWithFlags(&c.ev_outer[i], hipEventDisableTiming));
-        if (!c.ev_middle[i]) LSR_HIP(hipEventCreateWithFlags(&c.ev_middle[i], hipEventDisableTiming));
-    }
-    constexpr size_t kSlots = 3;                                       // workspace slots: F(c + 3) is enqueued behind I(c), which waits for M(c)
-    const size_t slot_words = std::min(chunk, batch) * vec_words;
-    if (c.ws_mid.count < slot_words * kSlots) c.ws_mid.allocate(slot_words * kSlots);
-    const bool sample = !d_e1 && d_keys;
-    if (sample && c.ws_e1_slots.count < slot_words * kSlots) c.ws_e1_slots.allocate(slot_words * kSlots);
-    hipStream_t outer = c.lane[0], middle = c.lane[1];
+}
+static void fork_lanes(const LweContext& c, hipStream_t s, int lanes) {
+    if (lanes <= 1) return;
     LSR_HIP(hipEventRecord(c.ev_fork, s));
-    LSR_HIP(hipStreamWaitEvent(outer, c.ev_fork, 0));
-    LSR_HIP(hipStreamWaitEvent(middle, c.ev_fork, 0));
-    const RoundConsts<ArithF64> cs{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64};
-    auto span = [&](size_t ci, size_t* first, size_t* now) { *first = ci * chunk; *now = std::min(chunk, batch - *first); };
-#ifdef LSR_LANE_TRACE   // development build (make VARIANT=trace EXTRA=-DLSR_LANE_TRACE): device timeline of the two lanes on stderr
-    struct Mark { char what; size_t chunk; hipEvent_t a, b; };
-    std::vector<Mark> marks;
-    auto mark_begin = [&](char what, size_t ci, hipStream_t st) { Mark m{what, ci, nullptr, nullptr}; LSR_HIP(hipEventCreate(&m.a)); LSR_HIP(hipEventCreate(&m.b));
-                                                                   LSR_HIP(hipEventRecord(m.a, st)); marks.push_back(m); };
-    auto mark_end = [&](hipStream_t st) { LSR_HIP(hipEventRecord(marks.back().b, st)); };
-#else
-    auto mark_begin = [&](char, size_t, hipStream_t) {};
-    auto mark_end = [&](hipStream_t) {};
-#endif
-    auto forward = [&](size_t ci) {
-        size_t first, now; span(ci, &first, &now);
-        uint64_t* const ws = c.ws_mid.ptr + (ci % kSlots) * slot_words;
-        mark_begin('F', ci, outer);
-        if (split88)
-            hipLaunchKernelGGL((cols8_forward<true, 16>), dim3(static_cast<unsigned>(now * k * 16)), dim3(c8_threads<16>()), 0, outer, ws, d_r + first * vec_words,
-                               (uint32_t)(now * k), c.ntt->mod, c.ntt->fwd_f64.ptr);
-        else
-            launch_top_round_forward(*c.ntt, ws, d_r + first * vec_words, now * k, outer);
-        mark_end(outer);
-        LSR_HIP(hipEventRecord(c.ev_outer[ci % LweContext::kRing], outer));
-    };
-    auto middle_stage = [&](size_t ci) {
-        size_t first, now; span(ci, &first, &now);
-        uint64_t* const ws = c.ws_mid.ptr + (ci % kSlots) * slot_words;
-        if (sample)      // the chunk's blinding residues: FP64-free integer work, on the ALU-bound lane
-            launch_gaussian(GaussianJob{c.ws_e1_slots.ptr + (ci % kSlots) * slot_words, d_keys + 4 * first, 0, k, kDomE1, c.n, now * k, c.q}, c.cdf.ptr,
-                            c.cdf_entries, middle);
-        LSR_HIP(hipStreamWaitEvent(middle, c.ev_outer[ci % LweContext::kRing], 0));
-        uint64_t* const out = d_u + first * vec_words;
-        mark_begin('M', ci, middle);
-        if (split88) {
-            switch (k) {
-                case 1: launch_mid8<1>(c, ws, out, now, middle); break;
-                case 2: launch_mid8<2>(c, ws, out, now, middle); break;
-                case 3: launch_mid8<3>(c, ws, out, now, middle); break;
-                default: launch_mid8<4>(c, ws, out, now, middle); break;
-            }
-        } else {
-            switch (k) {
-                case 1: launch_mid<1>(c, ws, out, now, middle); break;
-                case 2: launch_mid<2>(c, ws, out, now, middle); break;
-                case 3: launch_mid<3>(c, ws, out, now, middle); break;
-                default: launch_mid<4>(c, ws, out, now, middle); break;
-            }
-        }
-        mark_end(middle);
-        LSR_HIP(hipEventRecord(c.ev_middle[ci % LweContext::kRing], middle));
-    };
-    auto inverse = [&](size_t ci) {
-        size_t first, now; span(ci, &first, &now);
-        const uint64_t* blind = d_e1 ? d_e1 + first * vec_words : (sample ? c.ws_e1_slots.ptr + (ci % kSlots) * slot_words : nullptr);
-        LSR_HIP(hipStreamWaitEvent(outer, c.ev_middle[ci % LweContext::kRing], 0));
-        mark_begin('I', ci, outer);
-        if (split88)
-            hipLaunchKernelGGL((cols8_inverse<true, 16>), dim3(static_cast<unsigned>(now * k * 16)), dim3(c8_threads<16>()), 0, outer, d_u + first * vec_words,
-                               (uint32_t)(now * k), c.ntt->mod, c.ntt->inv_f64.ptr, cs, blind);
-        else
-            launch_top_round_inverse(*c.ntt, d_u + first * vec_words, now * k, outer, blind);
-        mark_end(outer);
-    };
-    // enqueue order respects the event rings (an event is re-recorded only after every wait on its previous record is enqueued)
-    forward(0);
-    for (size_t ci = 0; ci < chunks; ++ci) {
-        if (ci + 1 < chunks) forward(ci + 1);
-        middle_stage(ci);
-        inverse(ci);
+    for (int i = 1; i < lanes; ++i) LSR_HIP(hipStreamWaitEvent(c.side[i - 1], c.ev_fork, 0));
+}
+static void join_lanes(const LweContext& c, hipStream_t s, int lanes) {
+    for (int i = 1; i < lanes; ++i) {
+        LSR_HIP(hipEventRecord(c.ev_join[i - 1], c.side[i - 1]));
+        LSR_HIP(hipStreamWaitEvent(s, c.ev_join[i - 1], 0));
     }
-    LSR_HIP(hipGetLastError());
-    // join: the last kernel of the outer lane is I(chunks - 1), which waited for M(chunks - 1), the last kernel of the middle lane
-    LSR_HIP(hipEventRecord(c.ev_fork, outer));
-    LSR_HIP(hipStreamWaitEvent(s, c.ev_fork, 0));
-#ifdef LSR_LANE_TRACE
-    LSR_HIP(hipStreamSynchronize(outer));
-    LSR_HIP(hipStreamSynchronize(middle));
-    for (const Mark& m : marks) {
-        float t0 = 0, t1 = 0;
-        LSR_HIP(hipEventElapsedTime(&t0, marks.front().a, m.a));
-        LSR_HIP(hipEventElapsedTime(&t1, marks.front().a, m.b));
-        std::fprintf(stderr, "lane-trace %c(%zu) %7.1f -> %7.1f us\n", m.what, m.chunk, t0 * 1e3, t1 * 1e3);
-    }
-    for (const Mark& m : marks) { (void)hipEventDestroy(m.a); (void)hipEventDestroy(m.b); }
-#endif
 }
 
-// MIXED schedule of the 4 + 12 pipeline (n = 2^16, blinding residues given or absent; caller holds c.mutex): launch t carries the
+// MIXED schedule of the 4 + 12 pipeline (n = 2^16, blinding residues given; caller holds c.mutex): launch t carries the
 // middle stage of chunk t, the forward strided round of chunk t + 1 and the inverse strided round of chunk t - 1 as roles of one
-// kernel (lsr_commit_fused.hpp, mlwe_mixed), t = -1 .. chunks; two workspace slots alternate.  One stream, no events: the launch
+// kernel (lsr_commit_fused.hpp, mlwe_mixed), t = -1 .. chunks; two workspace slots alternate.  No events inside a lane: the launch
 // boundaries are the dependencies.
 template <int K>
-static void launch_mixed(const LweContext& c, const MixedJob& job, hipStream_t s, bool split88) {
+static void launch_mixed(const LweContext& c, const MixedJob& job, hipStream_t s) {
     const unsigned grid = (job.units_m + job.units_f + job.units_i) * 8u;
     if (!grid) return;
-    if (split88)
-        hipLaunchKernelGGL((mlwe_mixed88<K>), dim3(grid), dim3(512), 0, s, job, c.a_perm8.ptr, c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr,
-                           RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64});
-    else
-        hipLaunchKernelGGL((mlwe_mixed<K>), dim3(grid), dim3(kF8Threads), 0, s, job, c.a_perm.ptr, c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr,
-                           RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64});
+    hipLaunchKernelGGL((mlwe_mixed<K>), dim3(grid), dim3(kF8Threads), 0, s, job, c.a_perm.ptr, c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr,
+                       RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64});
     LSR_HIP(hipGetLastError());
 }
 
 static void mlwe_matvec_mixed(const LweContext& c, const uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s) {
     const uint32_t k = c.k;
     const size_t vec_words = (size_t)k << c.logn;
-    // 64 MiB chunks (32 rank-4 witness vectors): two lanes x two workspace slots x 64 MiB stay inside the 256 MiB Infinity Cache
-    const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_MIX_CHUNK_MIB", 64, 1, 4096);
-    const size_t chunk = std::max<size_t>(1, (chunk_mib << 20) / (vec_words * 8));
+    const size_t chunk = std::max<size_t>(1, kMixedChunkBytes / (vec_words * 8));
     const long chunks = static_cast<long>((batch + chunk - 1) / chunk);
-    // LAMBDA_SNARK_COMMIT_MIX_LANES (default 2): the chunks alternate between independent pipelines of mixed launches on their own
-    // streams (lane 0 = the caller's stream), so that the drain of one lane's launch is filled by the other's workgroups — all of
-    // one shape, so the dispatcher has no reason to starve either (3.05 -> 2.95 ms per 1024 vectors, profiles/r02_mixed_launch.txt)
-    const int lanes = static_cast<int>(std::min<long>(env_int("LAMBDA_SNARK_COMMIT_MIX_LANES", 2, 1, 3), chunks));
+    // the chunks alternate between independent pipelines of mixed launches on their own streams, so that the drain of one lane's
+    // launch is filled by the other's workgroups — all of one shape, so the dispatcher has no reason to starve either
+    // (3.05 -> 2.95 ms per 1024 vectors, profiles/r02_mixed_launch.txt)
+    const int lanes = static_cast<int>(std::min<long>(kMixedLanes, chunks));
     const size_t slot_words = std::min(chunk, batch) * vec_words;
     if (c.ws_mid.count < slot_words * 2 * lanes) c.ws_mid.allocate(slot_words * 2 * lanes);
-    while (c.n_side < lanes - 1) {
-        c.side[c.n_side] = create_side_stream(c.ntt->device, c.n_side);
-        LSR_HIP(hipEventCreateWithFlags(&c.ev_join[c.n_side], hipEventDisableTiming));
-        ++c.n_side;
-    }
-    if (lanes > 1) {
-        if (!c.ev_fork) LSR_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
-        LSR_HIP(hipEventRecord(c.ev_fork, s));
-        for (int i = 1; i < lanes; ++i) LSR_HIP(hipStreamWaitEvent(c.side[i - 1], c.ev_fork, 0));
-    }
-    // strided units that follow one middle unit in the block order.  The period (ratio + 1) must stay odd: blocks are dealt to the
-    // XCDs and their CUs round-robin, and with an even period the middle-stage workgroups pile up on a fraction of the CUs
-    // (profiles/r02_mixed_launch.txt: ratio 3 -> 5.5 ms, ratio 2 -> 3.07 ms per 1024 vectors)
-    // default (0): in proportion to the launch's work, rounded and bumped to the next even number (rank 4: 3 -> 4, rank 2: 2)
-    const int ratio_env = env_int("LAMBDA_SNARK_COMMIT_MIX_RATIO", 0, 0, 64);
-    // LAMBDA_SNARK_COMMIT_MIX_SPLIT=88: the roles of the 8 + 8 split (mlwe_mixed88) instead of the 4 + 12 split's
-    const bool split88 = c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_MIX_SPLIT", 412, 0, 412) == 88;
-    const int fgroups = split88 ? 1 : env_int("LAMBDA_SNARK_COMMIT_MIX_FGROUPS", 2, 1, 2);
+    ensure_side_streams(c, lanes);
+    fork_lanes(c, s, lanes);
     for (long t = -1;; ++t) {
         bool any = false;
         for (int lane = 0; lane < lanes; ++lane) {
@@ -749,7 +560,7 @@ static void mlwe_matvec_mixed(const LweContext& c, const uint64_t* d_r, const ui
                 job.f_src = d_r + first_of(t + 1) * vec_words;
                 job.f_polys = (uint32_t)(count_of(t + 1) * k);
                 // a unit = 8 workgroups of 512 lanes x 16 residues = one polynomial; two polynomials with two groups per lane
-                job.f_groups = (uint32_t)fgroups;
+                job.f_groups = kMixedForwardGroups;
                 job.units_f = (job.f_polys + job.f_groups - 1) / job.f_groups;
             }
             if (t >= 1 && valid(t - 1)) {
@@ -762,125 +573,63 @@ static void mlwe_matvec_mixed(const LweContext& c, const uint64_t* d_r, const ui
             if (!job.units_m && !units_s) continue;
             any = true;
             if (job.units_m && units_s) {
-                uint32_t ratio = (uint32_t)ratio_env;
-                if (!ratio) {
-                    ratio = std::max<uint32_t>(1u, (units_s + job.units_m / 2) / job.units_m);
-                    ratio += ratio & 1u;                      // odd period
-                }
+                // strided units that follow one middle unit in the block order, in proportion to the launch's work.  The period
+                // (ratio + 1) must stay odd: blocks are dealt to the XCDs and their CUs round-robin, and with an even period the
+                // middle-stage workgroups pile up on a fraction of the CUs (profiles/r02_mixed_launch.txt: ratio 3 -> 5.5 ms,
+                // ratio 2 -> 3.07 ms per 1024 vectors)
+                uint32_t ratio = std::max<uint32_t>(1u, (units_s + job.units_m / 2) / job.units_m);
+                ratio += ratio & 1u;
                 job.s_per_m = ratio;
                 job.periods = std::min(job.units_m, units_s / job.s_per_m);
             }
             hipStream_t st = lane == 0 ? s : c.side[lane - 1];
             switch (k) {
-                case 1: launch_mixed<1>(c, job, st, split88); break;
-                case 2: launch_mixed<2>(c, job, st, split88); break;
-                case 3: launch_mixed<3>(c, job, st, split88); break;
-                default: launch_mixed<4>(c, job, st, split88); break;
+                case 1: launch_mixed<1>(c, job, st); break;
+                case 2: launch_mixed<2>(c, job, st); break;
+                case 3: launch_mixed<3>(c, job, st); break;
+                default: launch_mixed<4>(c, job, st); break;
             }
         }
         if (!any && t >= 0) break;
     }
-    for (int i = 1; i < lanes; ++i) {
-        LSR_HIP(hipEventRecord(c.ev_join[i - 1], c.side[i - 1]));
-        LSR_HIP(hipStreamWaitEvent(s, c.ev_join[i - 1], 0));
-    }
+    join_lanes(c, s, lanes);
 }
 
 // Fused pipeline (caller holds c.mutex): per chunk of witness vectors
 //   top forward round r -> workspace | 12 forward stages x k, A_hat^T product, 12 inverse stages x k -> u | top inverse round (+ e1)
-// with the chunks dealt round-robin to side streams, so that the FP64-bound middle kernel of one chunk runs beside the
-// HBM-bound outer rounds of its neighbours.  d_r is only read.
-// d_e1 == NULL && d_keys != NULL: the blinding residues of a chunk are sampled (domain 5, per-vector keys d_keys[batch][4]) into
-// a chunk-sized buffer on the chunk's stream right before its transforms — no [batch][k][n] array of e1 ever exists, and the
-// sampling of one chunk runs beside the transforms of its neighbours.
+// with the chunks dealt round-robin to two lanes.  d_r is only read.
+// d_e1 == NULL && d_keys != NULL: the blinding residues are SAMPLED inside the two strided rounds of a chunk (domain 5, per-vector
+// keys d_keys[batch][4]; the forward round draws the first half of the rows into an int8 side slot, the inverse round the other
+// half) — no [batch][k][n] array of e1 ever exists.  Tables with more than 127 entries (sigma > ~13.7) sample everything in the
+// inverse round.
 static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s,
                               const uint64_t* d_keys = nullptr) {
-    // Alternative pipelines for n = 2^16, kept selectable (bit-exact, tests/test_commitment_gpu.py; measurements in
-    // profiles/r02_commit_split_88.txt): LAMBDA_SNARK_COMMIT_SPLIT=88 — the 8 + 8 split with the barrier-free middle stage —
-    // ties with the default 4 + 12 split (3.22-3.31 ms per 1024 rank-4 vectors either way); LAMBDA_SNARK_COMMIT_TWO_LANE=1 adds
-    // the two-lane schedule, which is slower today because the outer passes crawl at one workgroup per CU.
     // default for n = 2^16 with the blinding residues given: mixed launches (one kernel, three roles; see mlwe_matvec_mixed)
-    if (c.logn == 16 && d_e1 && !d_keys && env_int("LAMBDA_SNARK_COMMIT_MIXED", 1, 0, 1) && !env_int("LAMBDA_SNARK_COMMIT_TWO_LANE", 0, 0, 1) &&
-        env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) != 88) {
+    if (c.logn == 16 && d_e1 && !d_keys && c.tuning.mixed) {
         mlwe_matvec_mixed(c, d_r, d_e1, d_u, batch, s);
-        return;
-    }
-    if (env_int("LAMBDA_SNARK_COMMIT_TWO_LANE", 0, 0, 1)) {
-        mlwe_matvec_two_lane(c, d_r, d_e1, d_u, batch, s, d_keys, c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) == 88);
         return;
     }
     const uint32_t k = c.k;
     const size_t vec_words = (size_t)k << c.logn;
-    const int want = env_int("LAMBDA_SNARK_COMMIT_STREAMS", 2, 1, LweContext::kMaxSide);
-    // default chunk: 128 MiB with the blinding residues given, 64 MiB when they are sampled on the way (3.60 -> 3.52 ms per 1024
-    // rank-4 vectors; profiles/r02_mixed_launch.txt item 13)
-    const size_t chunk_mib = (size_t)env_int("LAMBDA_SNARK_COMMIT_CHUNK_MIB", (!d_e1 && d_keys) ? 64 : 128, 1, 4096);
-    const size_t chunk = std::max<size_t>(1, (chunk_mib << 20) / (vec_words * 8));
-    const int streams = static_cast<int>(std::min<size_t>((size_t)want, (batch + chunk - 1) / chunk));
-    // lane 0 is the caller's stream itself, lanes 1.. are side streams: every stream a process opens competes for the runtime's few
-    // hardware queues (four by default), and two lanes that land on one queue overlap nothing
-    while (c.n_side < streams - 1) {
-        c.side[c.n_side] = create_side_stream(c.ntt->device, c.n_side);
-        LSR_HIP(hipEventCreateWithFlags(&c.ev_join[c.n_side], hipEventDisableTiming));
-        ++c.n_side;
-    }
-    if (!c.ev_fork) LSR_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+    const bool sample = !d_e1 && d_keys;
+    const size_t chunk = std::max<size_t>(1, (sample ? kSampledChunkBytes : kFusedChunkBytes) / (vec_words * 8));
+    const int streams = static_cast<int>(std::min<size_t>((size_t)kFusedStreams, (batch + chunk - 1) / chunk));
+    ensure_side_streams(c, streams);
     auto lane = [&](size_t i) { return i == 0 ? s : c.side[i - 1]; };
     const size_t slot_words = std::min(chunk, batch) * vec_words;
     if (c.ws_mid.count < slot_words * streams) c.ws_mid.allocate(slot_words * streams);
-    const bool sample = !d_e1 && d_keys;
-    const bool split88 = c.a_perm8.ptr && env_int("LAMBDA_SNARK_COMMIT_SPLIT", 412, 0, 412) == 88;
-    const bool in_pass = sample && !split88 && env_int("LAMBDA_SNARK_COMMIT_SAMPLE_IN_PASS", 1, 0, 1);
-    const bool split_sampling = in_pass && c.cdf_entries <= 127 && env_int("LAMBDA_SNARK_COMMIT_SAMPLE_SPLIT", 1, 0, 1);
+    const bool split_sampling = sample && c.cdf_entries <= 127;
     const size_t side_words = slot_words / 16;                    // int8 samples of half the rows: 1/16 of the chunk's words
-    const size_t e1_words = !sample ? 0 : (in_pass ? (split_sampling ? side_words : 0) : slot_words);
-    if (e1_words && c.ws_e1_slots.count < e1_words * streams) c.ws_e1_slots.allocate(e1_words * streams);
-    if (streams > 1) LSR_HIP(hipEventRecord(c.ev_fork, s));
-    for (int i = 1; i < streams; ++i) LSR_HIP(hipStreamWaitEvent(lane(i), c.ev_fork, 0));
+    if (split_sampling && c.ws_e1_slots.count < side_words * streams) c.ws_e1_slots.allocate(side_words * streams);
+    fork_lanes(c, s, streams);
     size_t index = 0;
     for (size_t first = 0; first < batch; first += chunk, ++index) {
         const size_t now = std::min(chunk, batch - first);
         hipStream_t st = lane(index % streams);
         uint64_t* const ws = c.ws_mid.ptr + (index % streams) * slot_words;
-        const uint64_t* blind = d_e1 ? d_e1 + first * vec_words : nullptr;
-        // sampled blinding: in the 4 + 12 pipeline the last inverse round samples e1 itself (no array of e1 at all); the 8 + 8
-        // pipeline samples the chunk's residues into a slot first
-        const bool sample_in_pass = sample && !split88 && env_int("LAMBDA_SNARK_COMMIT_SAMPLE_IN_PASS", 1, 0, 1);
-        if (sample && !sample_in_pass) {
-            uint64_t* const slot = c.ws_e1_slots.ptr + (index % streams) * slot_words;
-            launch_gaussian(GaussianJob{slot, d_keys + 4 * first, 0, k, kDomE1, c.n, now * k, c.q}, c.cdf.ptr, c.cdf_entries, st);
-            blind = slot;
-        }
         uint64_t* const out = d_u + first * vec_words;
-        if (split88) {   // n = 2^16: bits 15..8 | bits 7..0, product, bits 0..7 | bits 8..15 (lsr_commit_fused.hpp, second half)
-            // column tile width of the outer passes (LAMBDA_SNARK_COMMIT_COLS = 16 | 32, default 32: 256-byte row segments)
-            const bool wide = env_int("LAMBDA_SNARK_COMMIT_COLS", 32, 16, 32) == 32;
-            const unsigned cols_grid = static_cast<unsigned>(now * k * (wide ? 8 : 16));
-            if (wide)
-                hipLaunchKernelGGL((cols8_forward<false, 32>), dim3(cols_grid), dim3(c8_threads<32>()), 0, st, ws, d_r + first * vec_words, (uint32_t)(now * k),
-                                   c.ntt->mod, c.ntt->fwd_f64.ptr);
-            else
-                hipLaunchKernelGGL((cols8_forward<false, 16>), dim3(cols_grid), dim3(c8_threads<16>()), 0, st, ws, d_r + first * vec_words, (uint32_t)(now * k),
-                                   c.ntt->mod, c.ntt->fwd_f64.ptr);
-            switch (k) {
-                case 1: launch_mid8<1>(c, ws, out, now, st); break;
-                case 2: launch_mid8<2>(c, ws, out, now, st); break;
-                case 3: launch_mid8<3>(c, ws, out, now, st); break;
-                default: launch_mid8<4>(c, ws, out, now, st); break;
-            }
-            if (wide)
-                hipLaunchKernelGGL((cols8_inverse<false, 32>), dim3(cols_grid), dim3(c8_threads<32>()), 0, st, out, (uint32_t)(now * k), c.ntt->mod,
-                                   c.ntt->inv_f64.ptr, RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64}, blind);
-            else
-                hipLaunchKernelGGL((cols8_inverse<false, 16>), dim3(cols_grid), dim3(c8_threads<16>()), 0, st, out, (uint32_t)(now * k), c.ntt->mod,
-                                   c.ntt->inv_f64.ptr, RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64}, blind);
-            LSR_HIP(hipGetLastError());
-            continue;
-        }
-        // split of the in-pass sampling (LAMBDA_SNARK_COMMIT_SAMPLE_SPLIT, default 1): the forward round samples the first half of the
-        // rows into a side slot as int8 (vec_words / 16 words per vector), the inverse round reads it and samples the other half
-        BlindSampler bs{d_keys + 4 * first, c.cdf.ptr, c.cdf_entries, k, kDomE1, nullptr};
-        if (sample_in_pass && split_sampling) bs.side = c.ws_e1_slots.ptr + (index % streams) * side_words;
+        BlindSampler bs{sample ? d_keys + 4 * first : nullptr, c.cdf.ptr, c.cdf_entries, k, kDomE1, nullptr};
+        if (split_sampling) bs.side = c.ws_e1_slots.ptr + (index % streams) * side_words;
         if (bs.side) launch_top_round_forward_sampling(*c.ntt, ws, d_r + first * vec_words, now * k, st, bs);
         else launch_top_round_forward(*c.ntt, ws, d_r + first * vec_words, now * k, st);
         switch (k) {
@@ -889,13 +638,10 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
             case 3: launch_mid<3>(c, ws, out, now, st); break;
             default: launch_mid<4>(c, ws, out, now, st); break;
         }
-        if (sample_in_pass) launch_top_round_inverse_sampled(*c.ntt, out, now * k, st, bs);
-        else launch_top_round_inverse(*c.ntt, out, now * k, st, blind);
+        if (sample) launch_top_round_inverse_sampled(*c.ntt, out, now * k, st, bs);
+        else launch_top_round_inverse(*c.ntt, out, now * k, st, d_e1 + first * vec_words);
     }
-    for (int i = 1; i < streams; ++i) {
-        LSR_HIP(hipEventRecord(c.ev_join[i - 1], lane(i)));
-        LSR_HIP(hipStreamWaitEvent(s, c.ev_join[i - 1], 0));
-    }
+    join_lanes(c, s, streams);
 }
 
 // u = INTT(A_hat^T NTT(r)) + e1 on device-resident [batch][k][n] arrays.  Unfused form: r is overwritten by NTT(r), which
@@ -904,7 +650,7 @@ static void mlwe_matvec_fused(const LweContext& c, const uint64_t* d_r, const ui
 static void mlwe_matvec_device(const LweContext& c, uint64_t* d_r, const uint64_t* d_e1, uint64_t* d_u, size_t batch, hipStream_t s,
                                bool allow_fused = false) {
     const uint32_t k = c.k;
-    if (allow_fused && c.a_perm.ptr && env_int("LAMBDA_SNARK_COMMIT_FUSED", 1, 0, 1)) {
+    if (allow_fused && c.a_perm.ptr) {
         mlwe_matvec_fused(c, d_r, d_e1, d_u, batch, s);
         return;
     }
@@ -1668,12 +1414,15 @@ int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uin
         // e1 sampled on the device from the per-vector raw-seed streams (domain 5), then added
         ctx->ws_key_host.resize(batch * 4);
         for (size_t j = 0; j < batch; ++j) lsr::key_words(lsr::expand_seed64(seeds[j]), ctx->ws_key_host.data() + 4 * j);
-        if (ctx->ws_keys.count < batch * 4) ctx->ws_keys.allocate(batch * 4);
+        // the workspace is sized BEFORE the keys are staged: ensure_workspace re-allocates ws_keys when the batch grows (round-2
+        // advisor: the upload used to precede it, so the sampler of an unfused context read a freed-and-reallocated buffer)
+        const bool fused = ctx->a_perm.ptr != nullptr;
+        if (!fused) lsr::ensure_workspace(*ctx, batch);
+        else if (ctx->ws_keys.count < batch * 4) ctx->ws_keys.allocate(batch * 4);
         LSR_HIP(hipMemcpyAsync(ctx->ws_keys.ptr, ctx->ws_key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
-        if (ctx->a_perm.ptr && lsr::env_int("LAMBDA_SNARK_COMMIT_FUSED", 1, 0, 1)) {
+        if (fused) {
             lsr::mlwe_matvec_fused(*ctx, d_r, nullptr, d_u, batch, s, ctx->ws_keys.ptr);
         } else {
-            lsr::ensure_workspace(*ctx, batch);
             lsr::launch_gaussian(lsr::GaussianJob{ctx->ws_e1.ptr, ctx->ws_keys.ptr, 0, ctx->k, lsr::kDomE1, ctx->n, batch * ctx->k, ctx->q}, ctx->cdf.ptr,
                                  ctx->cdf_entries, s);
             lsr::mlwe_matvec_device(*ctx, d_r, ctx->ws_e1.ptr, d_u, batch, s, false);

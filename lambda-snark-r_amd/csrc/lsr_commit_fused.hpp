@@ -483,450 +483,4 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mixed(MixedJob job, const 
     }
 }
 
-
-
-
-// =================================================================================================================================
-// 8 + 8 split for n = 2^16 (round 2, second design).  The 4 + 12 pipeline above leaves the fused stage FP64-bound while the two
-// strided rounds idle the ALUs at the memory floor; moving four stages of each direction into the outer passes costs those
-// passes nothing (they stay memory-bound) and takes a third of the butterflies out of the middle:
-//     cols8_forward   bits 15..8  r (canonical) -> workspace (raw)       16 columns x 256 rows per workgroup, one LDS exchange
-//     mlwe_mid8<K>    bits 7..0, A_hat^T product, bits 0..7              no workgroup exchange at all
-//     cols8_inverse   bits 8..15, n^-1, + e1, canonical store
-// With only index bits 0..7 inside, every butterfly of mlwe_mid8 pairs residues of one 256-block; a wavefront owns whole
-// blocks, so the regroupings between its three register rounds (bits [5,8), [2,5), [0,2)) are transposes between register
-// bits and LANE bits of the same wavefront: v_permlane32_swap / v_permlane16_swap for lane bits 5 and 4, DPP row shifts under
-// bank masks for lane bits 3 and 2, quad_perm for lane bit 1 (north_star: "ds_swizzle/ds_permute for the intra-wavefront
-// transpose stages").  No LDS tile, no barrier between rounds: the eight wavefronts of a workgroup only share the twiddle image.
-// Index algebra checked on the CPU by tools/experiments/sim_mid8.py.
-// =================================================================================================================================
-
-// COLS adjacent columns per workgroup (COLS * 16 lanes, 8 * COLS-byte row segments).  16: 256 lanes, 34 KiB of LDS; 32 (default
-// since the late round-2 measurement, profiles/r02_cols_width.txt): 512 lanes, 64 KiB — data movement alone 0.809 ms per 4096
-// polynomials against 0.867 ms with 128-byte segments and 0.779 ms for the strided round (tools/ubench_move2.hip).
-template <int COLS> constexpr int c8_threads() { return COLS * 16; }
-// tile position (row, col): COLS = 16 shifts every block of 16 rows by half a bank row so that the 32 lanes of a ds b64 group
-// (16 columns x 2 row groups) stay on distinct banks in both exchange patterns; with 32 columns a group is one contiguous row segment
-template <int COLS> __host__ __device__ constexpr uint32_t c8_slot(uint32_t row, uint32_t col) {
-    return row * COLS + (COLS == 16 ? 16u * (row >> 4) : 0u) + col;
-}
-template <int COLS> constexpr uint32_t c8_lds_words() { return 256u * COLS + (COLS == 16 ? 256u : 0u); }
-
-// forward: stages of polynomial index bits 15..8 on a tile of COLS adjacent columns x 256 rows (bits 8..15)
-// STREAM: every global access with the nt policy, so that the pass leaves the XCD's L2 to a co-resident middle stage (two-lane schedule)
-template <bool STREAM, int COLS>
-__device__ __forceinline__ void cols8_forward_body(uint32_t blk, uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t polys,
-                                                   const ModParams& p, const double* __restrict__ tw, double* __restrict__ lds) {
-    using A = ArithF64;
-    constexpr uint32_t CB = 256 / COLS;
-    const uint32_t t = threadIdx.x;
-    const uint32_t poly = blk / CB, cb = blk % CB;
-    if (poly >= polys) return;
-    const uint32_t col = t % COLS, rr = t / COLS;
-    const size_t base = ((size_t)poly << 16) + cb * COLS + col;
-    double v[16];
-    // round 1: registers = bits 12..15, this lane's row bits 8..11 = rr
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint64_t* const at = src + base + ((uint32_t)k << 12) + (rr << 8);
-        v[k] = A::load(STREAM ? __builtin_nontemporal_load(at) : *at, p);
-    }
-#pragma unroll
-    for (int j = 3; j >= 0; --j) {
-        const int half = 1 << j;
-#pragma unroll
-        for (int u = 0; u < (1 << (3 - j)); ++u) {
-            const double w = tw[(1 << (3 - j)) + u];
-#pragma unroll
-            for (int l = 0; l < half; ++l) A::ct(v[(u << (j + 1)) | l], v[((u << (j + 1)) | l) + half], w, p);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lds[c8_slot<COLS>(((uint32_t)k << 4) + rr, col)] = v[k];
-    __syncthreads();
-    // round 2: registers = bits 8..11, this lane's row bits 12..15 = rr
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[c8_slot<COLS>((rr << 4) + (uint32_t)k, col)];
-#pragma unroll
-    for (int j = 3; j >= 0; --j) {                    // polynomial bit b = 8 + j: table[2^(15-b) + (row >> (j + 1))]
-        const int half = 1 << j;
-#pragma unroll
-        for (int u = 0; u < (1 << (3 - j)); ++u) {
-            const double w = tw[(1u << (7 - j)) + (rr << (3 - j)) + u];
-#pragma unroll
-            for (int l = 0; l < half; ++l) A::ct(v[(u << (j + 1)) | l], v[((u << (j + 1)) | l) + half], w, p);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        uint64_t* const at = dst + base + (rr << 12) + ((uint32_t)k << 8);
-        if (STREAM) __builtin_nontemporal_store((uint64_t)__double_as_longlong(v[k]), at);
-        else *at = (uint64_t)__double_as_longlong(v[k]);
-    }
-}
-template <bool STREAM, int COLS>
-__global__ void __launch_bounds__(COLS * 16) cols8_forward(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t polys, ModParams p,
-                                                           const double* __restrict__ tw) {
-    __shared__ double lds[c8_lds_words<COLS>()];
-    cols8_forward_body<STREAM, COLS>(blockIdx.x, dst, src, polys, p, tw, lds);
-}
-
-// inverse: stages of bits 8..15 (Gentleman–Sande), n^-1 folded into the last one, + add (canonical residues, optional), canonical out
-template <bool STREAM, int COLS>
-__device__ __forceinline__ void cols8_inverse_body(uint32_t blk, uint64_t* __restrict__ data, uint32_t polys, const ModParams& p,
-                                                   const double* __restrict__ tw, const RoundConsts<ArithF64>& cs, const uint64_t* __restrict__ add,
-                                                   double* __restrict__ lds) {
-    using A = ArithF64;
-    constexpr uint32_t CB = 256 / COLS;
-    const uint32_t t = threadIdx.x;
-    const uint32_t poly = blk / CB, cb = blk % CB;
-    if (poly >= polys) return;
-    const uint32_t col = t % COLS, rr = t / COLS;
-    const size_t base = ((size_t)poly << 16) + cb * COLS + col;
-    double v[16];
-    // round 1: registers = bits 8..11, lane row bits 12..15 = rr
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = __longlong_as_double((long long)__builtin_nontemporal_load(data + base + (rr << 12) + ((uint32_t)k << 8)));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int half = 1 << j;
-#pragma unroll
-        for (int u = 0; u < (1 << (3 - j)); ++u) {
-            const double w = tw[(1u << (7 - j)) + (rr << (3 - j)) + u];
-#pragma unroll
-            for (int l = 0; l < half; ++l) A::gs(v[(u << (j + 1)) | l], v[((u << (j + 1)) | l) + half], w, p);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lds[c8_slot<COLS>((rr << 4) + (uint32_t)k, col)] = recentre_f64(v[k], p.qd, p.inv_qd);
-    __syncthreads();
-    // round 2: registers = bits 12..15, lane row bits 8..11 = rr
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = lds[c8_slot<COLS>(((uint32_t)k << 4) + rr, col)];
-    uint64_t blind[16];
-    if (add != nullptr) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint64_t* const at = add + base + ((uint32_t)k << 12) + (rr << 8);
-            blind[k] = STREAM ? __builtin_nontemporal_load(at) : *at;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int half = 1 << j;
-#pragma unroll
-        for (int u = 0; u < (1 << (3 - j)); ++u) {
-            const double w = tw[(1 << (3 - j)) + u];
-#pragma unroll
-            for (int l = 0; l < half; ++l) A::gs(v[(u << (j + 1)) | l], v[((u << (j + 1)) | l) + half], w, p);
-        }
-    }
-#pragma unroll
-    for (int l = 0; l < 8; ++l) A::gs_scaled(v[l], v[l + 8], cs.w_last_scaled, cs.n_inv, p);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint64_t out = add != nullptr ? A::store_reduced_plus(v[k], blind[k], p) : A::store_reduced(v[k], p);
-        __builtin_nontemporal_store(out, data + base + ((uint32_t)k << 12) + (rr << 8));
-    }
-}
-template <bool STREAM, int COLS>
-__global__ void __launch_bounds__(COLS * 16) cols8_inverse(uint64_t* __restrict__ data, uint32_t polys, ModParams p, const double* __restrict__ tw,
-                                                           RoundConsts<ArithF64> cs, const uint64_t* __restrict__ add) {
-    __shared__ double lds[c8_lds_words<COLS>()];
-    cols8_inverse_body<STREAM, COLS>(blockIdx.x, data, polys, p, tw, cs, add, lds);
-}
-
-// ---- the middle stage ----
-// WAVES = 8: one 512-lane workgroup per 4096-residue tile.  WAVES = 4: one 256-lane workgroup per HALF tile (index bit 11 from
-// the block index) with its LDS padded to 40.5 KiB, so that a CU takes exactly three of them (three waves per SIMD, at most 136
-// VGPRs each) and keeps one wave slot per SIMD, 104 VGPRs and 34 KiB of LDS free: room for one workgroup of cols8_forward /
-// cols8_inverse of a NEIGHBOURING chunk.  The FP64-bound middle stage and the memory-bound outer passes then run side by side
-// on every CU (tools/ubench_concurrency.hip: two such kernels on two streams overlap completely when the first one's
-// residency leaves room; the memory passes lose nothing at one workgroup per CU, profiles/r02_ubench_move2.txt).
-template <int WAVES> constexpr uint32_t m8_entries(int b) { return (1u << (11 - b)) / (8 / WAVES); }      // image entries of stage b
-template <int WAVES> constexpr uint32_t m8_image_offset(int b) {
-    uint32_t off = 0;
-    for (int s = 7; s > b; --s) off += m8_entries<WAVES>(s);
-    return off;
-}
-template <int WAVES> constexpr uint32_t m8_image_words() { return m8_image_offset<WAVES>(0) + m8_entries<WAVES>(0); }
-template <int WAVES> constexpr int m8_wave_bits() { return WAVES == 8 ? 3 : 2; }
-// tile index of register k of (virtual) lane T in the first (registers = bits 5..7) and last (registers = bits 0, 1, 4) layout;
-// T = lane | wave << 6 over the whole 4096-residue tile (with 4 waves per workgroup, T bit 8 = the workgroup's half)
-__host__ __device__ constexpr uint32_t m8_idx_a(uint32_t T, uint32_t k) { return ((T >> 1) & 31u) | (k << 5) | ((T & 1u) << 8) | ((T >> 6) << 9); }
-__host__ __device__ constexpr uint32_t m8_idx_c(uint32_t T, uint32_t k) {
-    return (k & 3u) | (((T >> 1) & 3u) << 2) | ((k >> 2) << 4) | (((T >> 3) & 7u) << 5) | ((T & 1u) << 8) | ((T >> 6) << 9);
-}
-// compacted lane bits that select a twiddle of round a / round b (the other lane bits do not reach above the stage's bit)
-__host__ __device__ constexpr uint32_t m8_sel_a(uint32_t T) { return (T & 1u) | ((T >> 6) << 1); }
-__host__ __device__ constexpr uint32_t m8_sel_b(uint32_t T) { return (T & 1u) | ((T >> 3) << 1); }
-// index bits 5..11 of this lane's residues once bits 2..4 are in registers (rounds b and c)
-__host__ __device__ constexpr uint32_t m8_high(uint32_t T) { return ((T >> 3) & 7u) | ((T & 1u) << 3) | ((T >> 6) << 4); }
-
-// one transpose step: register pair (lo = register bit clear, hi = set) against lane bit LB
-template <int LB>
-__device__ __forceinline__ void m8_swap_step(double& lo, double& hi, uint32_t t) {
-    const long long lb = __double_as_longlong(lo), hb = __double_as_longlong(hi);
-    unsigned a0 = (unsigned)lb, a1 = (unsigned)(lb >> 32), b0 = (unsigned)hb, b1 = (unsigned)(hb >> 32);
-    if constexpr (LB == 5) {          // v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second
-        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-        a0 = r0[0]; b0 = r0[1]; a1 = r1[0]; b1 = r1[1];
-    } else if constexpr (LB == 4) {   // v_permlane16_swap: odd rows of the first operand <-> even rows of the second
-        const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-        const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-        a0 = r0[0]; b0 = r0[1]; a1 = r1[0]; b1 = r1[1];
-    } else if constexpr (LB == 3 || LB == 2) {
-        // lanes with the bit set take the partner's `hi` into their `lo` (row_shr), lanes with it clear the partner's `lo` into
-        // their `hi` (row_shl); bank masks select the lanes: bit 3 -> banks {2,3} / {0,1}, bit 2 -> banks {1,3} / {0,2}
-        constexpr int N = 1 << LB;
-        constexpr int up = LB == 3 ? 0xC : 0xA, down = LB == 3 ? 0x3 : 0x5;
-        const int na0 = __builtin_amdgcn_update_dpp((int)a0, (int)b0, 0x110 + N, 0xF, up, false);
-        const int na1 = __builtin_amdgcn_update_dpp((int)a1, (int)b1, 0x110 + N, 0xF, up, false);
-        const int nb0 = __builtin_amdgcn_update_dpp((int)b0, (int)a0, 0x100 + N, 0xF, down, false);
-        const int nb1 = __builtin_amdgcn_update_dpp((int)b1, (int)a1, 0x100 + N, 0xF, down, false);
-        a0 = (unsigned)na0; a1 = (unsigned)na1; b0 = (unsigned)nb0; b1 = (unsigned)nb1;
-    } else {                          // lane bit 1: quad_perm [2,3,0,1] and a select
-        const bool upl = (t >> 1) & 1u;
-        const unsigned s0 = upl ? a0 : b0, s1 = upl ? a1 : b1;
-        const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp((int)s0, (int)s0, 0x4E, 0xF, 0xF, false);
-        const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp((int)s1, (int)s1, 0x4E, 0xF, 0xF, false);
-        a0 = upl ? r0 : a0; a1 = upl ? r1 : a1;
-        b0 = upl ? b0 : r0; b1 = upl ? b1 : r1;
-    }
-    lo = __longlong_as_double(((long long)a1 << 32) | a0);
-    hi = __longlong_as_double(((long long)b1 << 32) | b0);
-}
-// registers (bit 2, 1, 0) <-> lane bits (5, 4, 3): between the rounds of bits [5,8) and [2,5)
-__device__ __forceinline__ void m8_transpose_1(double (&v)[8], uint32_t t) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) m8_swap_step<5>(v[k], v[k + 4], t);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) if (!(k & 2)) m8_swap_step<4>(v[k], v[k + 2], t);
-#pragma unroll
-    for (int k = 0; k < 8; k += 2) m8_swap_step<3>(v[k], v[k + 1], t);
-}
-// registers (bit 1, 0) <-> lane bits (2, 1): between the rounds of bits [2,5) and [0,2)
-__device__ __forceinline__ void m8_transpose_2(double (&v)[8], uint32_t t) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) if (!(k & 2)) m8_swap_step<2>(v[k], v[k + 2], t);
-#pragma unroll
-    for (int k = 0; k < 8; k += 2) m8_swap_step<1>(v[k], v[k + 1], t);
-}
-
-// Twiddle image, both directions at once (image[0 .. W) forward, image[W .. 2W) inverse, W = m8_image_words): every lane
-// stores the 20 multipliers it will read (lanes that share one write the same value), every index is computed once and
-// nothing of the fill stays live across the kernel.  t = lane within the workgroup (addresses), T = lane within the tile (indices).
-template <int WAVES>
-__device__ __forceinline__ void m8_fill_twiddles(double* __restrict__ image, const double* forward, const double* inverse, uint32_t tile_pos, uint32_t t,
-                                                 uint32_t T) {
-    constexpr int WB = m8_wave_bits<WAVES>();
-    const rsrc_t tf = make_rsrc(forward, 8u << 16), ti = make_rsrc(inverse, 8u << 16);   // buffer loads: not hoisted, not spilled
-    const auto put = [&](uint32_t slot, uint32_t index) {
-        image[slot] = __longlong_as_double((long long)buf_load64(tf, index * 8u, 0));
-        image[m8_image_words<WAVES>() + slot] = __longlong_as_double((long long)buf_load64(ti, index * 8u, 0));
-    };
-    const uint32_t sa = m8_sel_a(T), h = m8_high(T), low = (T >> 1) & 3u;
-    const uint32_t la = m8_sel_a(t), lb = m8_sel_b(t);
-#pragma unroll
-    for (int b = 7; b >= 5; --b)
-#pragma unroll
-        for (uint32_t u = 0; u < (1u << (7 - b)); ++u)
-            put(m8_image_offset<WAVES>(b) + (la | (u << (1 + WB))), (1u << (15 - b)) + (tile_pos >> (b + 1)) + (sa << (7 - b)) + u);
-#pragma unroll
-    for (int b = 4; b >= 2; --b)
-#pragma unroll
-        for (uint32_t u = 0; u < (1u << (4 - b)); ++u)
-            put(m8_image_offset<WAVES>(b) + (lb | (u << (4 + WB))), (1u << (15 - b)) + (tile_pos >> (b + 1)) + (h << (4 - b)) + u);
-#pragma unroll
-    for (uint32_t g = 0; g < 2; ++g)      // bit 1: the registers above it hold bit 4 (g); bits 2, 3 come from lanes 1, 2
-        put(m8_image_offset<WAVES>(1) + (t | (g << (6 + WB))), (1u << 14) + (tile_pos >> 2) + (low | (g << 2) | (h << 3)));
-#pragma unroll
-    for (uint32_t u = 0; u < 4; ++u)      // bit 0: u = bit 1 | bit 4 << 1
-        put(m8_image_offset<WAVES>(0) + (t | (u << (6 + WB))), (1u << 15) + (tile_pos >> 1) + ((u & 1u) | (low << 1) | ((u >> 1) << 3) | (h << 4)));
-}
-
-// a_perm8[tile][i][c][kp][lane][e] = (double) a_hat[i][c][tile * 4096 + m8_idx_c(lane, 2 kp + e)]
-static __global__ void __launch_bounds__(256) m8_permute_matrix_kernel(double* __restrict__ a_perm, const uint64_t* __restrict__ a_hat, uint32_t k, int logn) {
-    const uint64_t total = (uint64_t)k * k << logn;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
-        const uint32_t e = g & 1u, lane = (g >> 1) & 511u, kp = (g >> 10) & 3u;
-        const uint64_t rest = g >> 12;
-        const uint32_t c = rest % k, i = (rest / k) % k;
-        const uint64_t tile = rest / ((uint64_t)k * k);
-        const uint64_t x = (tile << 12) + m8_idx_c(lane, 2 * kp + e);
-        a_perm[g] = f64_from_u52(a_hat[(((uint64_t)i * k + c) << logn) + x]);
-    }
-}
-
-// LDS words of the kernel: the two images, padded for WAVES = 4 so that exactly three workgroups fit a CU (3 x 41472 B + the
-// 34816 B of a cols8 workgroup <= 163840 B < 4 x 41472 B)
-template <int WAVES> constexpr uint32_t m8_lds_words() { return WAVES == 8 ? 2 * m8_image_words<8>() : 41472u / 8u; }
-
-template <int K, int WAVES>
-__device__ __forceinline__ void mlwe_mid8_body(uint32_t blk, const uint64_t* __restrict__ rws, uint64_t* __restrict__ u, const double* __restrict__ a_perm,
-                                               uint32_t vectors, const ModParams& p, const double* __restrict__ fwd_tw,
-                                               const double* __restrict__ inv_tw, double* __restrict__ image_lds) {
-    static_assert(2 * m8_image_words<WAVES>() <= m8_lds_words<WAVES>(), "twiddle images must fit");
-    constexpr int WB = m8_wave_bits<WAVES>();
-    const double* image = image_lds;                              // forward half first, inverse half for the second phase
-    const uint32_t t = threadIdx.x;
-    // (witness vector j, tile, half).  Workgroups b and b + 8 share an XCD under the observed round-robin placement (speed only):
-    // an XCD sees tiles {x, x + 8}, 1 MiB of a_perm8, which stays in its L2.
-    uint32_t rest = blk >> 3;
-    const uint32_t tile = (blk & 7u) | ((rest & 1u) << 3);        // n = 2^16: 16 tiles per polynomial
-    rest >>= 1;
-    uint32_t half = 0;
-    if constexpr (WAVES == 4) { half = rest & 1u; rest >>= 1; }
-    const uint32_t j = rest;
-    if (j >= vectors) return;
-    const uint32_t T = t | (half << 8);                           // lane within the 4096-residue tile
-    const uint32_t tile_pos = tile << 12;
-    const uint32_t base_a = m8_idx_a(T, 0);
-    const uint32_t la = m8_sel_a(t), lb = m8_sel_b(t);
-    const auto tw_a = [&](int s) {
-        return s == 0 ? image[m8_image_offset<WAVES>(7) + la] : (s < 3 ? image[m8_image_offset<WAVES>(6) + (la | ((uint32_t)(s - 1) << (1 + WB)))]
-                                                                        : image[m8_image_offset<WAVES>(5) + (la | ((uint32_t)(s - 3) << (1 + WB)))]);
-    };
-    const auto tw_b = [&](int s) {
-        return s == 0 ? image[m8_image_offset<WAVES>(4) + lb] : (s < 3 ? image[m8_image_offset<WAVES>(3) + (lb | ((uint32_t)(s - 1) << (4 + WB)))]
-                                                                        : image[m8_image_offset<WAVES>(2) + (lb | ((uint32_t)(s - 3) << (4 + WB)))]);
-    };
-    double acc[K][8];
-#pragma unroll
-    for (int c = 0; c < K; ++c)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[c][k] = 0.0;
-
-    m8_fill_twiddles<WAVES>(image_lds, fwd_tw, inv_tw, tile_pos, t, T);
-    __syncthreads();
-#pragma unroll 1
-    for (int i = 0; i < K; ++i) {
-        // the twiddle image does not change inside the loop: without this the compiler hoists its twenty reads out of it (40 VGPRs)
-        // and spills accumulators instead
-        asm volatile("" ::: "memory");
-        double v[8];
-        {
-            const rsrc_t src = make_rsrc(rws + ((((size_t)j * K + i) << p.logn) + tile_pos), 4096u * 8u);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = __longlong_as_double((long long)buf_load64<LSR_F8_LOAD_AUX>(src, base_a * 8u, (uint32_t)k * 256u));
-        }
-        f8_forward_round(v, tw_a, p);                     // bits 7, 6, 5
-        m8_transpose_1(v, t);
-        f8_forward_round(v, tw_b, p);                     // bits 4, 3, 2
-        m8_transpose_2(v, t);
-        {                                                 // bits 1, 0: registers (bit 4 | bit 1 | bit 0)
-            const double* const t1 = image + m8_image_offset<WAVES>(1) + t;
-            const double* const t0 = image + m8_image_offset<WAVES>(0) + t;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const double w = t1[g << (6 + WB)];
-                ArithF64::ct(v[4 * g], v[4 * g + 2], w, p);
-                ArithF64::ct(v[4 * g + 1], v[4 * g + 3], w, p);
-            }
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) ArithF64::ct(v[2 * q4], v[2 * q4 + 1], t0[q4 << (6 + WB)], p);
-        }
-        {   // acc[c] += A_hat[i][c] o r_hat_i: rolling window of four 16-byte matrix loads (as in mlwe_mid_fused8)
-            double2 a[4];
-            const rsrc_t slab = make_rsrc(a_perm + ((((size_t)tile * K + i) * K) << 12), (uint32_t)K * 4u * 512u * 16u);
-            const auto fetch = [&](int c, int kp) {
-                uint64_t lo, hi;
-                buf_load128(slab, T * 16u, (uint32_t)(c * 4 + kp) * 8192u, lo, hi);
-                return make_double2(__longlong_as_double((long long)lo), __longlong_as_double((long long)hi));
-            };
-#pragma unroll
-            for (int kp = 0; kp < 4; ++kp) a[kp] = fetch(0, kp);
-            static_for<0, K>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-#pragma unroll
-                for (int kp = 0; kp < 4; ++kp) {
-                    const double2 cur = a[kp];
-                    if constexpr (c + 1 < K) a[kp] = fetch(c + 1, kp);
-                    acc[c][2 * kp] += mulmod_f64(v[2 * kp], cur.x, p.qd, p.inv_qd);
-                    acc[c][2 * kp + 1] += mulmod_f64(v[2 * kp + 1], cur.y, p.qd, p.inv_qd);
-                }
-            });
-        }
-    }
-    image = image_lds + m8_image_words<WAVES>();          // the same lambdas now read the inverse multipliers
-    static_for<0, K>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        double x[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = recentre_f64(acc[c][k], p.qd, p.inv_qd);
-        {                                                 // bits 0, 1 (|x| <= 2 q afterwards)
-            const double* const t1 = image + m8_image_offset<WAVES>(1) + t;
-            const double* const t0 = image + m8_image_offset<WAVES>(0) + t;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) ArithF64::gs(x[2 * q4], x[2 * q4 + 1], t0[q4 << (6 + WB)], p);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const double w = t1[g << (6 + WB)];
-                ArithF64::gs(x[4 * g], x[4 * g + 2], w, p);
-                ArithF64::gs(x[4 * g + 1], x[4 * g + 3], w, p);
-            }
-        }
-        m8_transpose_2(x, t);
-        f8_inverse_round<true>(x, tw_b, p);               // bits 2, 3, 4: 16 q -> q/2
-        m8_transpose_1(x, t);
-        f8_inverse_round<true>(x, tw_a, p);               // bits 5, 6, 7: 4 q -> q/2, what cols8_inverse expects
-        const rsrc_t dst = make_rsrc(u + ((((size_t)j * K + c) << p.logn) + tile_pos), 4096u * 8u);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) buf_store64<LSR_F8_STORE_AUX>(dst, base_a * 8u, (uint32_t)k * 256u, (uint64_t)__double_as_longlong(x[k]));
-    });
-}
-
-template <int K>
-__global__ void __launch_bounds__(512, 4) mlwe_mid8_w8(const uint64_t* __restrict__ rws, uint64_t* __restrict__ u, const double* __restrict__ a_perm,
-                                                       uint32_t vectors, ModParams p, const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
-    __shared__ double image_lds[m8_lds_words<8>()];
-    mlwe_mid8_body<K, 8>(blockIdx.x, rws, u, a_perm, vectors, p, fwd_tw, inv_tw, image_lds);
-}
-// 136 VGPRs: three of these waves per SIMD leave 512 - 3 x 136 = 104 registers, what one wave of cols8_inverse needs
-template <int K>
-__global__ void __launch_bounds__(256, 3) __attribute__((amdgpu_num_vgpr(136)))
-mlwe_mid8_w4(const uint64_t* __restrict__ rws, uint64_t* __restrict__ u, const double* __restrict__ a_perm, uint32_t vectors, ModParams p,
-             const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
-    __shared__ double image_lds[m8_lds_words<4>()];
-    mlwe_mid8_body<K, 4>(blockIdx.x, rws, u, a_perm, vectors, p, fwd_tw, inv_tw, image_lds);
-}
-
-
-// Mixed launch of the 8 + 8 split (same scheme and block order as mlwe_mixed): roles = barrier-free middle stage mlwe_mid8 (bits 7..0),
-// cols8_forward of the next chunk, cols8_inverse (+ e1) of the previous one — all 512-lane workgroups, 64-65 KB of LDS.
-// a_perm8 layout.  `job.f_groups` is ignored (one 32-column tile per workgroup).
-template <int K>
-__global__ void __launch_bounds__(512, 4) mlwe_mixed88(MixedJob job, const double* __restrict__ a_perm8, ModParams p, const double* __restrict__ fwd_tw,
-                                                       const double* __restrict__ inv_tw, RoundConsts<ArithF64> cs) {
-    constexpr uint32_t kPool = m8_lds_words<8>() > c8_lds_words<32>() ? m8_lds_words<8>() : c8_lds_words<32>();
-    __shared__ double pool[kPool];                                    // one LDS block, whichever role the workgroup plays
-    const uint32_t x = blockIdx.x >> 3, sub = blockIdx.x & 7u;
-    const uint32_t per = job.s_per_m + 1u, inter = job.periods * per;
-    bool middle;
-    uint32_t unit;
-    if (x < inter) {
-        const uint32_t q = x / per, rem = x - q * per;
-        middle = rem == 0;
-        unit = middle ? q : q * job.s_per_m + rem - 1u;
-    } else {
-        const uint32_t y = x - inter, left_m = job.units_m - job.periods;
-        middle = y < left_m;
-        unit = middle ? job.periods + y : job.periods * job.s_per_m + (y - left_m);
-    }
-    if (middle) {
-        mlwe_mid8_body<K, 8>(unit * 8u + sub, job.m_ws, job.m_out, a_perm8, job.m_vectors, p, fwd_tw, inv_tw, pool);
-        return;
-    }
-    const uint32_t alt = job.units_f < job.units_i ? job.units_f : job.units_i;
-    bool forward;
-    uint32_t idx;
-    if (unit < 2u * alt) { forward = !(unit & 1u); idx = unit >> 1; }
-    else { forward = job.units_f > alt; idx = alt + (unit - 2u * alt); }
-    __builtin_amdgcn_s_setprio(3);
-    if (forward) cols8_forward_body<false, 32>(idx * 8u + sub, job.f_dst, job.f_src, job.f_polys, p, fwd_tw, pool);
-    else cols8_inverse_body<false, 32>(idx * 8u + sub, job.i_data, job.i_polys, p, inv_tw, cs, job.i_add, pool);
-}
-
 }  // namespace lsr

@@ -441,8 +441,12 @@ __device__ __forceinline__ void strided_round_body(uint64_t* __restrict__ data, 
         extern __shared__ uint64_t lds_words[];
         uint64_t* const cdf63 = lds_words;
         uint64_t* const tile_words = lds_words + ((bs.entries + 1u) & ~1u);
-        for (uint32_t i = threadIdx.x; i < bs.entries; i += kThreads) cdf63[i] = bs.cdf[i] >> 1;
-        __syncthreads();
+        const bool in_lanes = lane_table_steps(bs.entries) != 0u;            // the table in the wavefront's lanes (cdt_search), else in LDS
+        if (!in_lanes) {
+            for (uint32_t i = threadIdx.x; i < bs.entries; i += kThreads) cdf63[i] = bs.cdf[i] >> 1;
+            __syncthreads();
+        }
+        const LaneTable tab = in_lanes ? lane_table_load(bs.cdf, bs.entries) : LaneTable{0u, 0u};
         const size_t g0 = (size_t)blockIdx.x * kThreads;               // workgroup-uniform: polynomial and first column
         const uint32_t poly = (uint32_t)(g0 >> lo), low0 = (uint32_t)(g0 & (((size_t)1 << lo) - 1));
         const uint64_t* const key = bs.keys + 4 * (size_t)(poly / bs.components);
@@ -457,7 +461,7 @@ __device__ __forceinline__ void strided_round_body(uint64_t* __restrict__ data, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) u[i] = w[i] >> 1;
             uint32_t magnitude[8];
-            cdt_scan<8>(cdf63, bs.entries, u, magnitude);
+            cdt_magnitudes(tab, cdf63, bs.entries, u, magnitude);
             if constexpr (SM == 3) {                                    // int8 tile [row][256 columns]: eight samples = one LDS word
                 uint64_t packed = 0;
 #pragma unroll

@@ -14,14 +14,23 @@ namespace lsr {
 
 constexpr int kSamplerThreads = 256;
 
-// One lane = one ChaCha block = eight samples.  The CDT table sits in LDS at 63-bit precision (lsr_sampler.hpp).
+// One lane = one ChaCha block = eight samples.  The CDT table sits in the lanes of the wavefront (lsr_sampler.hpp, cdt_search) or,
+// when it has more than 64 entries, in LDS at 63-bit precision.  Lanes past the end of the job run the cipher and the search like
+// everyone else (the lane table needs every lane active) and skip the store.
 __device__ __forceinline__ void gaussian_body(const GaussianJob& job, const uint64_t* __restrict__ cdf_global, uint32_t entries) {
     extern __shared__ uint64_t cdf[];
-    for (uint32_t i = threadIdx.x; i < entries; i += kSamplerThreads) cdf[i] = cdf_global[i] >> 1;
-    __syncthreads();
+    const bool in_lanes = lane_table_steps(entries) != 0u;
+    if (!in_lanes) {
+        for (uint32_t i = threadIdx.x; i < entries; i += kSamplerThreads) cdf[i] = cdf_global[i] >> 1;
+        __syncthreads();
+    }
+    const LaneTable tab = in_lanes ? lane_table_load(cdf_global, entries) : LaneTable{0u, 0u};
     const uint64_t blocks_per_object = (job.samples + kSamplesPerBlock - 1) / kSamplesPerBlock;
-    const uint64_t gid = (uint64_t)blockIdx.x * kSamplerThreads + threadIdx.x;
-    if (gid >= blocks_per_object * job.objects) return;
+    const uint64_t lanes = blocks_per_object * job.objects;
+    if (lanes == 0) return;                                               // an empty job of a three-job launch: uniform exit
+    const uint64_t gid_raw = (uint64_t)blockIdx.x * kSamplerThreads + threadIdx.x;
+    const bool live = gid_raw < lanes;
+    const uint64_t gid = live ? gid_raw : lanes - 1;
     // lane -> (object, block): ring degrees are powers of two, so the usual case is a shift; a software 64-bit division per
     // lane (three of them) was a tenth of this kernel
     uint64_t object, block;
@@ -38,7 +47,8 @@ __device__ __forceinline__ void gaussian_body(const GaussianJob& job, const uint
 #pragma unroll
     for (int s = 0; s < 8; ++s) u[s] = w[s] >> 1;
     uint32_t magnitude[8];
-    cdt_scan<8>(cdf, entries, u, magnitude);
+    cdt_magnitudes(tab, cdf, entries, u, magnitude);
+    if (!live) return;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         if ((uint64_t)s >= left) break;

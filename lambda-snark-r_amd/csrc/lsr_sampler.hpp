@@ -69,6 +69,48 @@ __device__ __forceinline__ void cdt_scan(const uint64_t* cdf63, uint32_t entries
     }
 }
 
+// The same count as a branch-free BINARY SEARCH over a table that lives in the lanes of the wavefront (round 3): lane l holds
+// entry l (63-bit, padded with 2^63 - 1, which is never below u), and a probe is a ds_bpermute_b32 gather — the LDS crossbar, no LDS
+// memory, no banks, so neither the instruction stream nor any memory access pattern depends on the secret words, exactly as in
+// the linear pass.  STEPS = 5 serves tables of <= 32 entries (sigma <= ~3.4: every reference parameter set), STEPS = 6 <= 64
+// entries; a sample costs 3 STEPS VALU + 2 STEPS DS instructions instead of 2 (entries - 1) VALU ones, and the gathers run on the
+// LDS pipe beside the cipher's VALU work: 209 -> 276 G samples/s with the ChaCha20 stream (tools/ubench_sampler.hip,
+// profiles/r03_ubench_sampler.txt: the cipher alone 327 G/s).  EVERY lane of the wavefront must be active (an inactive source
+// lane reads as zero).  The table is non-decreasing (a cumulative sum), which is all the search needs.
+struct LaneTable {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ uint32_t lane_table_steps(uint32_t entries) { return entries <= 32u ? 5u : (entries <= 64u ? 6u : 0u); }   // 0: use cdt_scan
+// cdf: the 64-bit table (global or LDS); entries: scanned entries (the last one is all ones)
+__device__ __forceinline__ LaneTable lane_table_load(const uint64_t* cdf, uint32_t entries) {
+    const uint32_t l = threadIdx.x & 63u;
+    const uint64_t c = l < entries ? cdf[l] >> 1 : (~0ull >> 1);
+    return LaneTable{(uint32_t)c, (uint32_t)(c >> 32)};
+}
+template <int STEPS, int COUNT>
+__device__ __forceinline__ void cdt_search(const LaneTable& tab, const uint64_t (&u)[COUNT], uint32_t (&magnitude)[COUNT]) {
+#pragma unroll
+    for (int s = 0; s < COUNT; ++s) {
+        int at = ((1 << (STEPS - 1)) - 1) * 4;              // byte address of the probed lane: (found + step - 1) * 4
+#pragma unroll
+        for (int step = 1 << (STEPS - 1); step >= 1; step >>= 1) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)tab.lo);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)tab.hi);
+            const bool below = (((uint64_t)hi << 32) | lo) < u[s];
+            at += step > 1 ? (below ? 2 * step : -2 * step) : (below ? 4 : 0);
+        }
+        magnitude[s] = (uint32_t)at >> 2;
+    }
+}
+// magnitudes of the eight samples of one stream block, by whichever form the table's size admits (wavefront-uniform choice)
+__device__ __forceinline__ void cdt_magnitudes(const LaneTable& tab, const uint64_t* cdf63_lds, uint32_t entries, const uint64_t (&u)[8],
+                                               uint32_t (&magnitude)[8]) {
+    const uint32_t steps = lane_table_steps(entries);
+    if (steps == 5u) cdt_search<5, 8>(tab, u, magnitude);
+    else if (steps == 6u) cdt_search<6, 8>(tab, u, magnitude);
+    else cdt_scan<8>(cdf63_lds, entries, u, magnitude);
+}
+
 // sign applied to a magnitude without a branch (utils.cpp:114-120): residue in [0,q), or two's-complement int64 when q == 0
 __device__ __forceinline__ uint64_t gaussian_value(uint32_t magnitude, uint64_t word, uint64_t q) {
     const uint64_t m = magnitude;

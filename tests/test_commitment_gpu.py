@@ -373,17 +373,12 @@ def test_fused_pipeline_every_rank_and_degree(pkg, oracle, n, k, batch):
     lctx.close()
 
 
-@pytest.mark.parametrize("env", [{"LAMBDA_SNARK_COMMIT_SPLIT": "88"}, {"LAMBDA_SNARK_COMMIT_SPLIT": "88", "LAMBDA_SNARK_COMMIT_MID_WAVES": "4"},
-                                 {"LAMBDA_SNARK_COMMIT_SPLIT": "88", "LAMBDA_SNARK_COMMIT_MID_WAVES": "4", "LAMBDA_SNARK_COMMIT_TWO_LANE": "1"},
-                                 {"LAMBDA_SNARK_COMMIT_FUSED": "0"},
-                                 {"LAMBDA_SNARK_COMMIT_SAMPLE_IN_PASS": "0"}, {"LAMBDA_SNARK_COMMIT_SAMPLE_SPLIT": "0"},
-                                 {"LAMBDA_SNARK_COMMIT_TWO_LANE": "1"},
-                                 {"LAMBDA_SNARK_COMMIT_TWO_LANE": "1", "LAMBDA_SNARK_COMMIT_OUTER_CUS": "12"},
-                                 {"LAMBDA_SNARK_COMMIT_STREAMS": "1"}, {"LAMBDA_SNARK_COMMIT_STREAMS": "3", "LAMBDA_SNARK_COMMIT_STREAM_MODE": "1"}])
+@pytest.mark.parametrize("env", [{"LAMBDA_SNARK_COMMIT_FUSED": "0"}, {"LAMBDA_SNARK_COMMIT_MIXED": "0"}])
 def test_alternative_commit_pipelines_agree(pkg, oracle, env, monkeypatch):
-    """The selectable pipelines of the n = 2^16 matrix–vector product — the 8 + 8 split with the barrier-free middle stage
-    (8- and 4-wave workgroups), the two-lane schedule on either split (plain and CU-masked lanes), the unfused round-1 kernels,
-    blinding sampled into a slot / wholly inside the last inverse round instead of split over the two strided rounds, one and three chunk lanes — give the oracle's words."""
+    """The two pipeline switches the library still reads (once, when a context is created; round 3 removed the round-2 experiment
+    knobs): the unfused round-1 kernels and the three-launch schedule give the oracle's words, with the blinding residues sampled on the
+    device and given.  The unfused sampled call runs on a FRESH context with a batch that grows the workspace: the stream keys are
+    staged after the workspace is sized (round-2 advisor: use of a re-allocated key buffer)."""
     import torch
     for key, value in env.items():
         monkeypatch.setenv(key, value)
@@ -398,6 +393,13 @@ def test_alternative_commit_pipelines_agree(pkg, oracle, env, monkeypatch):
         d_u = torch.empty_like(d_r)
         assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), None, d_u.data_ptr(), batch, seeds.ctypes.data, s) == 0
         torch.cuda.synchronize()
+        d_r.copy_(torch.from_numpy(r.view(np.int64)))                                  # the unfused kernels transform r in place
+        d_e1 = torch.empty_like(d_r)
+        assert lctx._lib.lsr_lwe_sample_blinding_device(lctx.handle, d_e1.data_ptr(), batch, seeds.ctypes.data, s) == 0
+        d_u2 = torch.empty_like(d_r)
+        assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), d_e1.data_ptr(), d_u2.data_ptr(), batch, None, s) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(d_u, d_u2), (env, k)
         for j in (0, 63, 64, batch - 1):
             e1 = np.stack([oracle.sample_gaussian_seeded(n, 3.19, int(seeds[j]), 5, i) for i in range(k)])
             e1 = np.where(e1 < 0, e1 + q, e1).astype(np.uint64)
@@ -405,21 +407,20 @@ def test_alternative_commit_pipelines_agree(pkg, oracle, env, monkeypatch):
         lctx.close()
 
 
-@pytest.mark.parametrize("ratio,fgroups,lanes,split", [("4", "2", "2", "412"), ("2", "1", "1", "412"), ("7", "1", "3", "412"), ("4", "1", "2", "88"),
-                                                        ("2", "1", "1", "88")])
-def test_mixed_launch_schedule_agrees(pkg, oracle, ratio, fgroups, lanes, split, monkeypatch):
-    """LAMBDA_SNARK_COMMIT_MIXED=1: the middle stage of chunk t, the forward strided round of chunk t + 1 and the inverse strided
-    round (+ e1) of chunk t - 1 as roles of one launch (mlwe_mixed; with MIX_SPLIT=88 the roles of the 8 + 8 split, mlwe_mixed88).  Ragged batches over one, two and three chunks, ranks 4, 2, 1,
-    several block-order ratios: every word of u equals the default three-launch pipeline's, sampled vectors equal the oracle's."""
+def test_mixed_launch_schedule_agrees(pkg, oracle, monkeypatch):
+    """The default schedule for n = 2^16 with the blinding residues given: the middle stage of chunk t, the forward strided round of
+    chunk t + 1 and the inverse strided round (+ e1) of chunk t - 1 as roles of one launch (mlwe_mixed).  Ragged batches over one, two
+    and several chunks, ranks 1-4: every word of u equals the three-launch pipeline's (a second context of the same keys created with
+    LAMBDA_SNARK_COMMIT_MIXED=0), sampled vectors equal the oracle's."""
     import torch
     q, n = 17592182243329, 65536
     s = torch.cuda.current_stream().cuda_stream
-    monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_RATIO", ratio)
-    monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_FGROUPS", fgroups)
-    monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_LANES", lanes)
-    monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIX_SPLIT", split)
     for k, batch in ((4, 150), (4, 64), (4, 5), (2, 70), (1, 299), (3, 65), (4, 33)):
+        monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIXED", "0")
+        three = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xFACE + k)
+        monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIXED", "1")
         lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xFACE + k)
+        monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIXED", "0")       # read at creation only: changing it now must not matter
         a_hat = lctx.public_matrix()
         d_r = torch.empty((batch, k, n), dtype=torch.int64, device="cuda")
         assert lctx._lib.lsr_fill_splitmix_device(d_r.data_ptr(), batch, k * n, 0xC0FFEE + 11 * k, q, s) == 0
@@ -428,18 +429,17 @@ def test_mixed_launch_schedule_agrees(pkg, oracle, ratio, fgroups, lanes, split,
         assert lctx._lib.lsr_lwe_sample_blinding_device(lctx.handle, d_e1.data_ptr(), batch, seeds.ctypes.data, s) == 0
         d_u0, d_u1 = torch.empty_like(d_r), torch.empty_like(d_r)
         keep = d_r.clone()
-        monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIXED", "0")
-        assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), d_e1.data_ptr(), d_u0.data_ptr(), batch, None, s) == 0
-        monkeypatch.setenv("LAMBDA_SNARK_COMMIT_MIXED", "1")
+        assert three._lib.lsr_mlwe_matvec_batch_device(three.handle, d_r.data_ptr(), d_e1.data_ptr(), d_u0.data_ptr(), batch, None, s) == 0
         assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), d_e1.data_ptr(), d_u1.data_ptr(), batch, None, s) == 0
         torch.cuda.synchronize()
         assert torch.equal(d_r, keep), "the fused pipelines only read r"
-        assert torch.equal(d_u0, d_u1), (k, batch, ratio)
+        assert torch.equal(d_u0, d_u1), (k, batch)
         for j in sorted({0, min(63, batch - 1), min(64, batch - 1), batch - 1}):
             r_j = d_r[j].cpu().numpy().view(np.uint64)
             e1_j = d_e1[j].cpu().numpy().view(np.uint64)
             assert np.array_equal(d_u1[j].cpu().numpy().view(np.uint64), oracle.mlwe_matvec(q, n, k, a_hat, r_j, e1_j)), (k, batch, j)
         lctx.close()
+        three.close()
 
 
 def test_config3_full_size_device_resident(pkg, oracle):
@@ -470,6 +470,7 @@ def test_config3_full_size_device_resident(pkg, oracle):
         assert np.array_equal(d_u[j].cpu().numpy().view(np.uint64), want), f"witness vector {j}"
     # every output is a canonical residue
     assert int(d_u.max().item()) < q and int(d_u.min().item()) >= 0
+    sampled_u = d_u.clone()
     # linearity with e1 = 0 over the whole batch
     half = batch // 2
     d_r.copy_(torch.from_numpy(r.view(np.int64)))
@@ -480,6 +481,19 @@ def test_config3_full_size_device_resident(pkg, oracle):
     assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_sum.data_ptr(), zeros.data_ptr(), d_us.data_ptr(), half, None, s) == 0
     torch.cuda.synchronize()
     assert torch.equal(d_us, (d_u[:half] + d_u[half:]) % q)
+    # the DEFAULT schedule (mixed launches: e1 given as an array) at the same full size: every word equals the e1-sampled pipeline's
+    # output above, and the picks equal the oracle's (round-2 verdict: the mixed default was only linearity-checked at 1024 vectors)
+    del d_us, d_sum, zeros
+    d_e1 = torch.empty_like(d_r)
+    assert lctx._lib.lsr_lwe_sample_blinding_device(lctx.handle, d_e1.data_ptr(), batch, seeds.ctypes.data, s) == 0
+    d_um = torch.empty_like(d_r)
+    assert lctx._lib.lsr_mlwe_matvec_batch_device(lctx.handle, d_r.data_ptr(), d_e1.data_ptr(), d_um.data_ptr(), batch, None, s) == 0
+    torch.cuda.synchronize()
+    for j in picks:
+        e1 = np.stack([oracle.sample_gaussian_seeded(n, 3.19, int(seeds[j]), 5, i) for i in range(k)])
+        e1 = np.where(e1 < 0, e1 + q, e1).astype(np.uint64)
+        assert np.array_equal(d_um[j].cpu().numpy().view(np.uint64), oracle.mlwe_matvec(q, n, k, a_hat, r[j], e1)), f"mixed schedule, witness vector {j}"
+    assert torch.equal(d_um, sampled_u), "mixed launches (e1 given) and the three-launch schedule (e1 sampled in the pass) disagree"
     lctx.close()
 
 
