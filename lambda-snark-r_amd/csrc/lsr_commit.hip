@@ -25,14 +25,15 @@
 #include "lambda_snark/commitment.h"
 #include "lsr_arith.hpp"
 #include "lsr_commit_fused.hpp"
+#include "lsr_commit_tile.hpp"
 #include "lsr_keys.hpp"
 #include "lsr_runtime.hpp"
 #include "lsr_sampler.hpp"
 
 namespace lsr {
 
-constexpr uint64_t kWireMagic = 0x313030304352534CULL;   // "LSRC0001"
-constexpr size_t kHeaderWords = 5;                        // data[0] + 4 header words
+constexpr uint64_t kWireMagic = kRowMagic;                // "LSRC0001" (lsr_commit_tile.hpp)
+constexpr size_t kHeaderWords = kRowHeaderWords;          // data[0] + 4 header words
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -189,21 +190,6 @@ __global__ void __launch_bounds__(256) rsub_mod_kernel(uint64_t* __restrict__ ds
     }
 }
 
-// floor((hi:lo) / q) for a dividend below 2^61 * 2^21 (quotient fits 64 bits), by Barrett + fix-up
-__device__ __forceinline__ uint64_t div128_by_q(uint64_t hi, uint64_t lo, const ModParams& p) {
-    const uint64_t c1 = __umul64hi(lo, p.barrett_lo);
-    const uint64_t m1_lo = lo * p.barrett_hi, m1_hi = __umul64hi(lo, p.barrett_hi);
-    const uint64_t m2_lo = hi * p.barrett_lo, m2_hi = __umul64hi(hi, p.barrett_lo);
-    uint64_t s = c1 + m1_lo;
-    uint64_t carry = s < c1;
-    const uint64_t s2 = s + m2_lo;
-    carry += s2 < s;
-    uint64_t quot = hi * p.barrett_hi + m1_hi + m2_hi + carry;
-    uint64_t rem = lo - quot * p.q;
-    while (rem >= p.q) { rem -= p.q; ++quot; }
-    return quot;
-}
-
 // flag |= OR_i ( round(t * w_i / q) mod t ) xor msg_i   — OR-of-XOR compare of commitment.cpp:223-228
 // minuend (optional, canonical residues): decode minuend_i - w_i instead of w_i
 __global__ void __launch_bounds__(256) decode_compare_kernel(const uint64_t* __restrict__ w, const uint64_t* __restrict__ msg, uint64_t msg_len,
@@ -213,11 +199,7 @@ __global__ void __launch_bounds__(256) decode_compare_kernel(const uint64_t* __r
     uint64_t diff = 0;
     if (i < msg_len) {
         const uint64_t wi = minuend ? (minuend[i] >= w[i] ? minuend[i] - w[i] : minuend[i] + p.q - w[i]) : w[i];
-        const uint64_t lo0 = wi * t, hi0 = __umul64hi(wi, t);
-        const uint64_t lo = lo0 + (p.q >> 1);
-        const uint64_t hi = hi0 + (lo < lo0);
-        const uint64_t decoded = div128_by_q(hi, lo, p) % t;
-        diff = decoded ^ msg[i];                       // raw message word (commitment.cpp:224)
+        diff = decode_slot(wi, t, p) ^ msg[i];         // raw message word (commitment.cpp:224)
     }
     if (diff) atomicOr(flag, (unsigned long long)diff);
 }
@@ -230,10 +212,7 @@ __global__ void __launch_bounds__(256) decode_compare_batch_kernel(const uint64_
     if (gid >= count * msg_len) return;
     const uint64_t j = gid / msg_len, i = gid - j * msg_len;
     const uint64_t wi = w[(j << logn) + i];
-    const uint64_t lo0 = wi * t, hi0 = __umul64hi(wi, t);
-    const uint64_t lo = lo0 + (p.q >> 1);
-    const uint64_t hi = hi0 + (lo < lo0);
-    const uint64_t diff = (div128_by_q(hi, lo, p) % t) ^ msgs[gid];
+    const uint64_t diff = decode_slot(wi, t, p) ^ msgs[gid];
     if (diff) atomicOr(&flags[j], (unsigned long long)diff);
 }
 
@@ -264,14 +243,21 @@ struct LweContext {
     mutable std::mutex mutex;
     mutable lsr::DeviceBuffer<uint64_t> ws_r, ws_e1, ws_e2, ws_u, ws_v, ws_dm, ws_keys;   // ws_keys: [batch][4]
     mutable lsr::DeviceBuffer<unsigned long long> ws_flag;
-    mutable size_t ws_batch = 0;
+    mutable size_t ws_batch = 0, ws_in_batch = 0;
     mutable std::vector<uint64_t> ws_key_host;    // source of an asynchronous upload: must outlive the call that fills it
     // pinned host staging for the gather of a batch (two bulk D2H copies instead of two per commitment)
     mutable uint64_t* host_stage = nullptr;
     mutable size_t host_stage_words = 0;
     // fused matrix–vector pipeline (lsr_commit_fused.hpp): lane-major copy of A_hat, per-lane chunk workspaces, side streams
     static constexpr int kMaxSide = 2;
-    lsr::DeviceBuffer<double> a_perm;
+    lsr::DeviceBuffer<double> a_perm;       // [tile][k][k]: the A^T product (n = 2^16 / 2^17)
+    // full commitments and openings on the tile pipeline (lsr_commit_tile.hpp; n = 4096, 2^16, 2^17):
+    lsr::DeviceBuffer<double> ab_perm;      // [tile][k][k + 1]: A^T and b_hat in one pass (n = 4096: k <= 4; larger n: k <= 3)
+    lsr::DeviceBuffer<double> b_perm;       // [tile][k][1]: b_hat alone (larger n, k = 4: the scalar component is a second pass)
+    lsr::DeviceBuffer<double> s_perm;       // [tile][k][1]: s_hat, the one-column matrix of an opening
+    mutable lsr::DeviceBuffer<uint64_t> ws_rows;                    // wire rows of a chunk on their way to host allocations
+    mutable lsr::DeviceBuffer<unsigned long long> ws_vflags;        // openings: per-row OR of decoded ^ claimed
+    mutable lsr::DeviceBuffer<uint32_t> ws_vbad;                    // openings: per-row "not a canonical commitment of this context"
     mutable lsr::DeviceBuffer<uint64_t> ws_mid, ws_e1_slots;
     mutable hipStream_t side[kMaxSide] = {nullptr, nullptr};
     mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr};
@@ -335,7 +321,18 @@ static void matvec_square(const LweContext& c, uint64_t* out, const uint64_t* ma
     }
 }
 
+// staging of a batch's stream keys and messages (every commit path), grown on demand
+static void ensure_input_space(const LweContext& c, size_t batch) {
+    if (batch <= c.ws_in_batch) return;
+    c.ws_dm.allocate(batch * c.n);   // message slots of a batch (at most n per commitment); verify's message buffer
+    c.ws_keys.allocate(batch * 4);
+    LSR_HIP(hipMemset(c.ws_keys.ptr, 0xA5, batch * 32));   // never a valid stale key: a use before the upload shows up in the parity tests
+    if (!c.ws_flag.ptr) c.ws_flag.allocate(1);
+    c.ws_in_batch = batch;
+}
+// arrays of the general (unfused) kernels
 static void ensure_workspace(const LweContext& c, size_t batch) {
+    ensure_input_space(c, batch);
     if (batch <= c.ws_batch) return;
     const size_t kn = (size_t)c.k * c.n;
     c.ws_r.allocate(batch * kn);
@@ -343,10 +340,6 @@ static void ensure_workspace(const LweContext& c, size_t batch) {
     c.ws_u.allocate(batch * kn);
     c.ws_e2.allocate(batch * c.n);
     c.ws_v.allocate(batch * c.n);
-    c.ws_dm.allocate(batch * c.n);   // message slots of a batch (at most n per commitment); verify's message buffer
-    c.ws_keys.allocate(batch * 4);
-    LSR_HIP(hipMemset(c.ws_keys.ptr, 0xA5, batch * 32));   // never a valid stale key: a use before the upload shows up in the parity tests
-    if (!c.ws_flag.ptr) c.ws_flag.allocate(1);
     c.ws_batch = batch;
 }
 
@@ -358,6 +351,12 @@ static bool fused_eligible(const LweContext& c) {
 static bool env_flag(const char* name, bool fallback) {
     const char* e = std::getenv(name);
     return (e && (e[0] == '0' || e[0] == '1') && e[1] == 0) ? e[0] == '1' : fallback;
+}
+
+// whole commitments / openings in one workgroup (lsr_commit_tile.hpp): the reference's ring degree, FP64 flavour, rank <= 4, a CDT
+// table that fits the lanes of a wavefront
+static bool tile_eligible(const LweContext& c) {
+    return c.tuning.fused && c.ntt->use_f64 && c.logn == 12 && c.k >= 1 && c.k <= 4 && c.cdf_entries <= 64;
 }
 
 static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_seed, int device, const ContextKeys* replicate = nullptr) {
@@ -420,10 +419,16 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
         launch_ntt(*c->ntt, e_hat.ptr, k, false, s);
         // b_hat[i] = sum_j A_hat[i][j] s_hat[j] + e_hat[i]
         matvec_square(*c, c->b_hat.ptr, c->a_hat.ptr, c->s_hat.ptr, e_hat.ptr, false, 1, s);
-        if (fused_eligible(*c)) {
-            c->a_perm.allocate((size_t)k * kn);
-            hipLaunchKernelGGL(f8_permute_matrix_kernel, dim3(grid_for((uint64_t)k * kn)), dim3(256), 0, s, c->a_perm.ptr, c->a_hat.ptr, k, c->logn);
+        auto permute = [&](DeviceBuffer<double>& out, const uint64_t* extra, uint32_t c0, uint32_t nc) {
+            out.allocate((size_t)nc * kn);
+            hipLaunchKernelGGL(f8_permute_matrix_kernel, dim3(grid_for((uint64_t)nc * kn)), dim3(256), 0, s, out.ptr, c->a_hat.ptr, extra, k, c0, nc, c->logn);
             LSR_HIP(hipGetLastError());
+        };
+        if (fused_eligible(*c)) permute(c->a_perm, nullptr, 0u, k);
+        if (tile_eligible(*c) || (fused_eligible(*c) && c->cdf_entries <= 64)) {
+            if (c->logn == 12 || k <= 3) permute(c->ab_perm, c->b_hat.ptr, 0u, k + 1);
+            else permute(c->b_perm, c->b_hat.ptr, k, 1u);
+            permute(c->s_perm, c->s_hat.ptr, k, 1u);
         }
         LSR_HIP(hipStreamSynchronize(s));
         LSR_HIP(hipMemset(sec_key.ptr, 0, 32));
@@ -451,7 +456,10 @@ static void destroy_lwe_context(LweContext* c) {
         c->a_hat.release(); c->s_hat.release(); c->b_hat.release(); c->cdf.release();
         c->ws_r.release(); c->ws_e1.release(); c->ws_e2.release(); c->ws_u.release(); c->ws_v.release();
         c->ws_dm.release(); c->ws_keys.release(); c->ws_flag.release();
-        c->a_perm.release(); c->ws_mid.release();
+        c->a_perm.release(); c->ab_perm.release(); c->b_perm.release(); c->ws_mid.release(); c->ws_rows.release();
+        c->ws_vflags.release(); c->ws_vbad.release();
+        if (c->s_perm.ptr) (void)hipMemset(c->s_perm.ptr, 0, c->s_perm.count * 8);
+        c->s_perm.release();
         if (c->ws_e1_slots.ptr) (void)hipMemset(c->ws_e1_slots.ptr, 0, c->ws_e1_slots.count * 8);
         c->ws_e1_slots.release();
         for (int i = 0; i < c->n_side; ++i) {
@@ -667,7 +675,7 @@ static void ensure_host_stage(const LweContext& c, size_t words) {
     if (c.host_stage) (void)hipHostFree(c.host_stage);
     c.host_stage = nullptr;
     c.host_stage_words = 0;
-    LSR_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host_stage), words * 8, hipHostMallocDefault));
+    LSR_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host_stage), words * 8, hipHostMallocPortable));   // any device of the node may DMA into it
     c.host_stage_words = words;
 }
 
@@ -676,58 +684,6 @@ static LweCommitment* new_commitment(size_t words) {
     out->len = words;
     out->data = new uint64_t[words];
     return out;
-}
-
-// u -> c.ws_u, v -> c.ws_v for `batch` commitments, enqueued on the context's stream
-static void commit_compute(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds) {
-    const uint32_t n = c.n, k = c.k;
-    ensure_workspace(c, batch);
-    hipStream_t s = work_stream(*c.ntt);
-    // host prep: the per-commitment stream keys (lsr_keys.hpp): seed == 0 => 256 bits of fresh entropy (commitment.h:52), else
-    // PRF(seed, context id, embedded message) — a reused seed never repeats the blinding across messages or contexts
-    std::vector<uint64_t>& key_host = c.ws_key_host;
-    key_host.resize(batch * 4);
-    const size_t copy = std::min<size_t>(msg_len, n);                       // commitment.cpp:146-149
-    for (size_t j = 0; j < batch; ++j) {
-        const StreamKey key = seeds && seeds[j] ? derive_commit_key(seeds[j], c.keys.id, messages + j * msg_len, copy, c.t) : fresh_key();
-        key_words(key, key_host.data() + 4 * j);
-    }
-    // only the first `copy` slots of each message matter; rows keep their msg_len pitch
-    DeviceBuffer<uint64_t> big_msgs;
-    uint64_t* d_msgs = c.ws_dm.ptr;
-    const uint64_t* d_keys = c.ws_keys.ptr;
-    const size_t in_words = batch * 4 + (copy ? batch * msg_len : 0);
-    if (in_words <= LweContext::kSmallInWords) {
-        // one upload from page-locked memory instead of two staged ones (every caller synchronises the stream before it returns, so
-        // the staging area is free again by the next call)
-        if (!c.host_in) {
-            LSR_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host_in), LweContext::kSmallInWords * 8, hipHostMallocDefault));
-            c.ws_in.allocate(LweContext::kSmallInWords);
-        }
-        std::memcpy(c.host_in, key_host.data(), batch * 32);
-        if (copy) std::memcpy(c.host_in + batch * 4, messages, batch * msg_len * 8);
-        LSR_HIP(hipMemcpyAsync(c.ws_in.ptr, c.host_in, in_words * 8, hipMemcpyHostToDevice, s));
-        d_keys = c.ws_in.ptr;
-        d_msgs = c.ws_in.ptr + batch * 4;
-    } else {
-        LSR_HIP(hipMemcpyAsync(c.ws_keys.ptr, key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
-        if (batch * msg_len > c.ws_dm.count) {
-            big_msgs.allocate(batch * msg_len);
-            d_msgs = big_msgs.ptr;
-        }
-        if (copy) LSR_HIP(hipMemcpyAsync(d_msgs, messages, batch * msg_len * 8, hipMemcpyHostToDevice, s));
-    }
-    launch_gaussian3(GaussianJob{c.ws_r.ptr, d_keys, 0, k, kDomR, n, batch * k, c.q}, GaussianJob{c.ws_e1.ptr, d_keys, 0, k, kDomE1, n, batch * k, c.q},
-                     GaussianJob{c.ws_e2.ptr, d_keys, 0, 1, kDomE2, n, batch, c.q}, c.cdf.ptr, c.cdf_entries, s);
-    mlwe_matvec_device(c, c.ws_r.ptr, c.ws_e1.ptr, c.ws_u.ptr, batch, s);    // leaves r_hat in ws_r
-    // v = INTT(<b_hat, r_hat>) + e2 + Delta m
-    matvec(c, c.ws_v.ptr, c.b_hat.ptr, c.ws_r.ptr, nullptr, 1, k, 0, 1, batch, s);
-    launch_ntt(*c.ntt, c.ws_v.ptr, batch, true, s);
-    const uint64_t vcount = (uint64_t)batch * n;
-    hipLaunchKernelGGL(finish_v_kernel, dim3(grid_for(vcount)), dim3(256), 0, s, c.ws_v.ptr, c.ws_e2.ptr, d_msgs, (uint64_t)msg_len, (uint64_t)copy,
-                       (uint32_t)c.logn, vcount, c.delta, c.t, c.q);
-    LSR_HIP(hipGetLastError());
-    if (big_msgs.ptr) LSR_HIP(hipStreamSynchronize(s));   // the oversized message buffer dies with this scope
 }
 
 // wire format rows [batch][5 + kn + n] assembled on the device (one contiguous copy back instead of a host-side scatter)
@@ -763,42 +719,135 @@ __global__ void __launch_bounds__(256) unpack_commitments_kernel(const uint64_t*
     }
 }
 
+// The per-commitment stream keys and the messages of a batch, staged on the device (enqueued on `s`).
+// Host prep (lsr_keys.hpp): seed == 0 => 256 bits of fresh entropy (commitment.h:52), else PRF(seed, context id, embedded message)
+// — a reused seed never repeats the blinding across messages or contexts.  Only the first `copy` slots of each message matter
+// (commitment.cpp:146-149); rows keep their msg_len pitch.
+struct StagedInputs {
+    const uint64_t* d_keys = nullptr;
+    const uint64_t* d_msgs = nullptr;
+    DeviceBuffer<uint64_t> big_msgs;       // a message batch larger than the context's scratch: dies with this object (after a sync)
+};
+static void stage_commit_inputs(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, hipStream_t s,
+                                StagedInputs* in) {
+    ensure_input_space(c, batch);
+    std::vector<uint64_t>& key_host = c.ws_key_host;
+    key_host.resize(batch * 4);
+    const size_t copy = std::min<size_t>(msg_len, c.n);
+    for (size_t j = 0; j < batch; ++j) {
+        const StreamKey key = seeds && seeds[j] ? derive_commit_key(seeds[j], c.keys.id, messages + j * msg_len, copy, c.t) : fresh_key();
+        key_words(key, key_host.data() + 4 * j);
+    }
+    const size_t in_words = batch * 4 + (copy ? batch * msg_len : 0);
+    if (in_words <= LweContext::kSmallInWords) {
+        // one upload from page-locked memory instead of two staged ones (every caller synchronises the stream before it returns, so
+        // the staging area is free again by the next call)
+        if (!c.host_in) {
+            LSR_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host_in), LweContext::kSmallInWords * 8, hipHostMallocPortable));
+            c.ws_in.allocate(LweContext::kSmallInWords);
+        }
+        std::memcpy(c.host_in, key_host.data(), batch * 32);
+        if (copy) std::memcpy(c.host_in + batch * 4, messages, batch * msg_len * 8);
+        LSR_HIP(hipMemcpyAsync(c.ws_in.ptr, c.host_in, in_words * 8, hipMemcpyHostToDevice, s));
+        in->d_keys = c.ws_in.ptr;
+        in->d_msgs = c.ws_in.ptr + batch * 4;
+        return;
+    }
+    LSR_HIP(hipMemcpyAsync(c.ws_keys.ptr, key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
+    uint64_t* d_msgs = c.ws_dm.ptr;
+    if (batch * msg_len > c.ws_dm.count) {
+        in->big_msgs.allocate(batch * msg_len);
+        d_msgs = in->big_msgs.ptr;
+    }
+    if (copy) LSR_HIP(hipMemcpyAsync(d_msgs, messages, batch * msg_len * 8, hipMemcpyHostToDevice, s));
+    in->d_keys = c.ws_keys.ptr;
+    in->d_msgs = d_msgs;
+}
+
+// General form (any degree, rank and arithmetic flavour the context supports): r, e1, e2 sampled into arrays, transforms and
+// products as separate kernels, the rows assembled at the end.  d_keys [batch][4], d_msgs [batch][msg_len] on the device.
+static void commit_rows_general(const LweContext& c, const uint64_t* d_msgs, size_t msg_len, size_t batch, const uint64_t* d_keys, uint64_t* d_rows,
+                                hipStream_t s) {
+    const uint32_t n = c.n, k = c.k;
+    const size_t copy = std::min<size_t>(msg_len, n);
+    ensure_workspace(c, batch);
+    launch_gaussian3(GaussianJob{c.ws_r.ptr, d_keys, 0, k, kDomR, n, batch * k, c.q}, GaussianJob{c.ws_e1.ptr, d_keys, 0, k, kDomE1, n, batch * k, c.q},
+                     GaussianJob{c.ws_e2.ptr, d_keys, 0, 1, kDomE2, n, batch, c.q}, c.cdf.ptr, c.cdf_entries, s);
+    mlwe_matvec_device(c, c.ws_r.ptr, c.ws_e1.ptr, c.ws_u.ptr, batch, s);    // leaves r_hat in ws_r
+    // v = INTT(<b_hat, r_hat>) + e2 + Delta m
+    matvec(c, c.ws_v.ptr, c.b_hat.ptr, c.ws_r.ptr, nullptr, 1, k, 0, 1, batch, s);
+    launch_ntt(*c.ntt, c.ws_v.ptr, batch, true, s);
+    const uint64_t vcount = (uint64_t)batch * n;
+    hipLaunchKernelGGL(finish_v_kernel, dim3(grid_for(vcount)), dim3(256), 0, s, c.ws_v.ptr, c.ws_e2.ptr, d_msgs, (uint64_t)msg_len, (uint64_t)copy,
+                       (uint32_t)c.logn, vcount, c.delta, c.t, c.q);
+    const uint64_t kn = (uint64_t)k * n, words = kHeaderWords + kn + n;
+    hipLaunchKernelGGL(pack_commitments_kernel, dim3(grid_for(batch * words)), dim3(256), 0, s, d_rows, c.ws_u.ptr, c.ws_v.ptr, kn, (uint64_t)n, (uint64_t)batch,
+                       c.q, c.t, n | ((uint64_t)k << 32));
+    LSR_HIP(hipGetLastError());
+}
+
+// n = 4096: one launch, one workgroup per commitment (lsr_commit_tile.hpp)
+template <int K>
+static void launch_commit_tile(const LweContext& c, const CommitTileJob& job, hipStream_t s) {
+    hipLaunchKernelGGL((commit_tile_kernel<K>), dim3(job.batch), dim3(kF8Threads), 0, s, job, c.ab_perm.ptr, c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr,
+                       RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64});
+    LSR_HIP(hipGetLastError());
+}
+static void commit_rows_tile(const LweContext& c, const uint64_t* d_msgs, size_t msg_len, size_t batch, const uint64_t* d_keys, uint64_t* d_rows, hipStream_t s) {
+    const size_t row_words = kHeaderWords + ((size_t)c.k + 1) * c.n;
+    for (size_t first = 0; first < batch; first += 0x40000000u) {            // grid limit: 2^30 workgroups per launch
+        const size_t now = std::min<size_t>(batch - first, 0x40000000u);
+        const CommitTileJob job{d_rows + first * row_words, d_keys + 4 * first, d_msgs + first * msg_len, (uint64_t)msg_len, (uint64_t)std::min<size_t>(msg_len, c.n),
+                                c.cdf.ptr, c.cdf_entries, (uint32_t)now, c.q, c.t, c.delta};
+        switch (c.k) {
+            case 1: launch_commit_tile<1>(c, job, s); break;
+            case 2: launch_commit_tile<2>(c, job, s); break;
+            case 3: launch_commit_tile<3>(c, job, s); break;
+            default: launch_commit_tile<4>(c, job, s); break;
+        }
+    }
+}
+
+// wire rows d_rows[batch][5 + (k + 1) n] of `batch` commitments from device-resident keys and messages, enqueued on `s` (caller
+// holds c.mutex): the reference's lwe_commit (commitment.cpp:138-164) for a whole batch without a byte of host traffic
+static void commit_rows_device(const LweContext& c, const uint64_t* d_msgs, size_t msg_len, size_t batch, const uint64_t* d_keys, uint64_t* d_rows,
+                               hipStream_t s) {
+    if (!batch) return;
+    if (c.ab_perm.ptr && c.logn == 12) commit_rows_tile(c, d_msgs, msg_len, batch, d_keys, d_rows, s);
+    else commit_rows_general(c, d_msgs, msg_len, batch, d_keys, d_rows, s);
+}
+
 // out_words: host array (the rows come back in one copy) or, with `to_device`, device memory the rows are assembled in
 static void commit_chunk_flat(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, uint64_t* out_words,
                               bool to_device) {
-    const uint64_t n = c.n, kn = (uint64_t)c.k * c.n, words = kHeaderWords + kn + n;
-    commit_compute(c, messages, msg_len, batch, seeds);
+    const size_t words = kHeaderWords + ((size_t)c.k + 1) * c.n;
     hipStream_t s = work_stream(*c.ntt);
-    DeviceBuffer<uint64_t> packed;
+    StagedInputs in;
+    stage_commit_inputs(c, messages, msg_len, batch, seeds, s, &in);
     uint64_t* rows = out_words;
     if (!to_device) {
-        packed.allocate(batch * words);
-        rows = packed.ptr;
+        if (c.ws_rows.count < batch * words) c.ws_rows.allocate(batch * words);
+        rows = c.ws_rows.ptr;
     }
-    hipLaunchKernelGGL(pack_commitments_kernel, dim3(grid_for(batch * words)), dim3(256), 0, s, rows, c.ws_u.ptr, c.ws_v.ptr, kn, n, (uint64_t)batch, c.q,
-                       c.t, n | ((uint64_t)c.k << 32));
-    LSR_HIP(hipGetLastError());
-    if (!to_device) LSR_HIP(hipMemcpyAsync(out_words, packed.ptr, batch * words * 8, hipMemcpyDeviceToHost, s));
+    commit_rows_device(c, in.d_msgs, msg_len, batch, in.d_keys, rows, s);
+    if (!to_device) LSR_HIP(hipMemcpyAsync(out_words, rows, batch * words * 8, hipMemcpyDeviceToHost, s));
     LSR_HIP(hipStreamSynchronize(s));
 }
 
 static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, LweCommitment** out) {
-    const uint32_t n = c.n, k = c.k;
-    const size_t kn = (size_t)k * n;
-    commit_compute(c, messages, msg_len, batch, seeds);
+    const size_t words = kHeaderWords + ((size_t)c.k + 1) * c.n;
     hipStream_t s = work_stream(*c.ntt);
-    // gather: u and v of the whole chunk come back in two bulk copies into pinned memory; the per-commitment arrays
-    // (which the ABI wants as separate new[] allocations, commitment.cpp:50-57) are filled from there by a few threads
-    const size_t words = kHeaderWords + kn + n;
-    const size_t stage_words = batch * (kn + n);
-    ensure_host_stage(c, stage_words);
-    uint64_t* const stage_u = c.host_stage;
-    uint64_t* const stage_v = c.host_stage + batch * kn;
-    LSR_HIP(hipMemcpyAsync(stage_u, c.ws_u.ptr, batch * kn * 8, hipMemcpyDeviceToHost, s));
-    LSR_HIP(hipMemcpyAsync(stage_v, c.ws_v.ptr, batch * (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    StagedInputs in;
+    stage_commit_inputs(c, messages, msg_len, batch, seeds, s, &in);
+    if (c.ws_rows.count < batch * words) c.ws_rows.allocate(batch * words);
+    commit_rows_device(c, in.d_msgs, msg_len, batch, in.d_keys, c.ws_rows.ptr, s);
+    // gather: the rows of the whole chunk come back in one bulk copy into pinned memory; the per-commitment arrays (which the ABI
+    // wants as separate new[] allocations, commitment.cpp:50-57) are filled from there by a few threads
+    ensure_host_stage(c, batch * words);
+    LSR_HIP(hipMemcpyAsync(c.host_stage, c.ws_rows.ptr, batch * words * 8, hipMemcpyDeviceToHost, s));
     std::vector<LweCommitment*> made(batch, nullptr);
     try {
-        for (size_t j = 0; j < batch; ++j) made[j] = new_commitment(words);   // overlaps the copies
+        for (size_t j = 0; j < batch; ++j) made[j] = new_commitment(words);   // overlaps the copy
         LSR_HIP(hipStreamSynchronize(s));
     } catch (...) {
         (void)hipStreamSynchronize(s);
@@ -808,16 +857,7 @@ static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t m
         throw;
     }
     auto fill = [&](size_t lo, size_t hi) {
-        for (size_t j = lo; j < hi; ++j) {
-            uint64_t* d = made[j]->data;
-            d[0] = 8ull * (words - 1);
-            d[1] = kWireMagic;
-            d[2] = (uint64_t)n | ((uint64_t)k << 32);
-            d[3] = c.q;
-            d[4] = c.t;
-            std::memcpy(d + kHeaderWords, stage_u + j * kn, kn * 8);
-            std::memcpy(d + kHeaderWords + kn, stage_v + j * n, (size_t)n * 8);
-        }
+        for (size_t j = lo; j < hi; ++j) std::memcpy(made[j]->data, c.host_stage + j * words, words * 8);
     };
     const size_t workers = std::min<size_t>(8, std::max<size_t>(1, (batch * words * 8) >> 22));   // one thread per ~4 MiB, at most 8
     if (workers <= 1) {
@@ -847,155 +887,154 @@ static bool parse_commitment(const LweContext& c, const LweCommitment* cm, const
     return true;
 }
 
+// flags[j] / bad[j] -> results[j] = -1 (not a canonical commitment of this context) / 1 (opens) / 0
+__global__ void __launch_bounds__(256) opening_verdict_kernel(const unsigned long long* __restrict__ flags, const uint32_t* __restrict__ bad,
+                                                               int* __restrict__ results, uint64_t count) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < count) results[j] = bad[j] ? -1 : (flags[j] == 0 ? 1 : 0);
+}
+
+template <int K>
+static void launch_verify_tile(const LweContext& c, const VerifyTileJob& job, hipStream_t s) {
+    hipLaunchKernelGGL((verify_tile_kernel<K>), dim3(job.count), dim3(kF8Threads), 0, s, job, c.s_perm.ptr, c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr,
+                       RoundConsts<ArithF64>{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64});
+    LSR_HIP(hipGetLastError());
+}
+
+// `count` openings from device-resident wire rows and claimed messages (1 <= msg_len <= n), enqueued on `s`; caller holds c.mutex.
+// Leaves the per-row OR of (decoded ^ claimed) in c.ws_vflags and the per-row "not a canonical commitment of this context" mark in
+// c.ws_vbad — lwe_verify_opening (commitment.cpp:200-232) for a whole batch:
+//   v - INTT(<s_hat, NTT(u)>) decoded slot-wise and compared with the message words as given.
+static void verify_rows_device(const LweContext& c, const uint64_t* d_rows, const uint64_t* d_msgs, size_t msg_len, size_t count, hipStream_t s) {
+    const uint32_t n = c.n, k = c.k;
+    const size_t kn = (size_t)k * n, row = kHeaderWords + kn + n;
+    if (c.ws_vflags.count < count) { c.ws_vflags.allocate(count); c.ws_vbad.allocate(count); }
+    LSR_HIP(hipMemsetAsync(c.ws_vflags.ptr, 0, count * sizeof(unsigned long long), s));
+    LSR_HIP(hipMemsetAsync(c.ws_vbad.ptr, 0, count * sizeof(uint32_t), s));
+    if (c.s_perm.ptr && c.logn == 12) {     // one launch, one workgroup per opening: the row is read once (lsr_commit_tile.hpp)
+        const VerifyTileJob job{d_rows, d_msgs, (uint64_t)msg_len, c.ws_vflags.ptr, c.ws_vbad.ptr, (uint32_t)count, c.q, c.t};
+        switch (k) {
+            case 1: launch_verify_tile<1>(c, job, s); break;
+            case 2: launch_verify_tile<2>(c, job, s); break;
+            case 3: launch_verify_tile<3>(c, job, s); break;
+            default: launch_verify_tile<4>(c, job, s); break;
+        }
+        return;
+    }
+    // general form: split the rows (header and canonicity checks on the way), transform, product, subtract, inverse, decode
+    ensure_workspace(c, count);
+    hipLaunchKernelGGL(unpack_commitments_kernel, dim3(grid_for(count * row)), dim3(256), 0, s, d_rows, c.ws_u.ptr, c.ws_v.ptr, c.ws_vbad.ptr, (uint64_t)kn,
+                       (uint64_t)n, (uint64_t)count, c.q, c.t, (uint64_t)n | ((uint64_t)k << 32));
+    launch_ntt(*c.ntt, c.ws_u.ptr, count * k, false, s);
+    launch_ntt(*c.ntt, c.ws_v.ptr, count, false, s);
+    matvec(c, c.ws_e2.ptr, c.s_hat.ptr, c.ws_u.ptr, nullptr, 1, k, 0, 1, count, s);            // <s_hat, u_hat>
+    hipLaunchKernelGGL(rsub_mod_kernel, dim3(grid_for(count * n)), dim3(256), 0, s, c.ws_e2.ptr, c.ws_v.ptr, (uint64_t)count * n, c.q);
+    launch_ntt(*c.ntt, c.ws_e2.ptr, count, true, s);
+    const uint64_t lanes = (uint64_t)count * msg_len;
+    hipLaunchKernelGGL(decode_compare_batch_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, c.ws_e2.ptr, d_msgs, (uint64_t)msg_len,
+                       (uint32_t)c.logn, (uint64_t)count, c.t, c.ntt->mod, c.ws_vflags.ptr);
+    LSR_HIP(hipGetLastError());
+}
+
+// openings per device pass of the host-pointer entry points: about 1 GiB of rows and scratch
+static size_t verify_chunk(const LweContext& c, size_t count) {
+    const size_t per_opening = (4 * (size_t)c.k + 5) * c.n * 8;
+    return std::max<size_t>(1, std::min<size_t>(count, (1ull << 30) / per_opening));
+}
+
+// rows (host, back to back) and messages -> results, `chunk` openings per pass; rows may live in pageable or pinned memory
+static void verify_host_rows(const LweContext& c, const uint64_t* rows, const uint64_t* messages, size_t msg_len, size_t count, int* results, hipStream_t s) {
+    const size_t row = kHeaderWords + ((size_t)c.k + 1) * c.n;
+    const size_t chunk = verify_chunk(c, count);
+    if (c.ws_rows.count < chunk * row) c.ws_rows.allocate(chunk * row);
+    DeviceBuffer<uint64_t> d_msgs(chunk * msg_len);
+    std::vector<unsigned long long> host_flags(chunk);
+    std::vector<uint32_t> host_bad(chunk);
+    for (size_t first = 0; first < count; first += chunk) {
+        const size_t now = std::min(chunk, count - first);
+        LSR_HIP(hipMemcpyAsync(c.ws_rows.ptr, rows + first * row, now * row * 8, hipMemcpyHostToDevice, s));
+        LSR_HIP(hipMemcpyAsync(d_msgs.ptr, messages + first * msg_len, now * msg_len * 8, hipMemcpyHostToDevice, s));
+        verify_rows_device(c, c.ws_rows.ptr, d_msgs.ptr, msg_len, now, s);
+        LSR_HIP(hipMemcpyAsync(host_flags.data(), c.ws_vflags.ptr, now * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipMemcpyAsync(host_bad.data(), c.ws_vbad.ptr, now * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipStreamSynchronize(s));
+        for (size_t j = 0; j < now; ++j) results[first + j] = host_bad[j] ? -1 : (host_flags[j] == 0 ? 1 : 0);
+    }
+}
+
 static int verify_opening(const LweContext& c, const LweCommitment* cm, const uint64_t* message, size_t msg_len) {
     const uint64_t* body = nullptr;
     if (!parse_commitment(c, cm, &body)) return -1;
-    const uint32_t n = c.n, k = c.k;
-    const size_t kn = (size_t)k * n;
-    for (size_t i = 0; i < kn + n; ++i)
-        if (body[i] >= c.q) return -1;                                      // not a canonical payload
-    if (msg_len > n) return 0;                                             // commitment.cpp:219-221
-    if (msg_len == 0) return 1;
-    DeviceGuard guard(c.device);
-    std::lock_guard<std::mutex> lock(c.mutex);
-    ensure_workspace(c, 1);
-    hipStream_t s = work_stream(*c.ntt);
-    // a single call is launch-bound: the body u || v goes up in one copy, v stays in the coefficient domain (by linearity
-    // v - INTT(<s_hat, NTT(u)>) is what the reference decodes) and the subtraction rides in the decode kernel — four kernels, not six
-    if (c.ws_body.count < kn + n) c.ws_body.allocate(kn + n);
-    LSR_HIP(hipMemcpyAsync(c.ws_body.ptr, body, (kn + n) * 8, hipMemcpyHostToDevice, s));
-    LSR_HIP(hipMemcpyAsync(c.ws_dm.ptr, message, msg_len * 8, hipMemcpyHostToDevice, s));
-    LSR_HIP(hipMemsetAsync(c.ws_flag.ptr, 0, sizeof(unsigned long long), s));
-    launch_ntt(*c.ntt, c.ws_body.ptr, k, false, s);
-    matvec(c, c.ws_e2.ptr, c.s_hat.ptr, c.ws_body.ptr, nullptr, 1, k, 0, 1, 1, s);      // <s_hat, u_hat>
-    launch_ntt(*c.ntt, c.ws_e2.ptr, 1, true, s);
-    hipLaunchKernelGGL(decode_compare_kernel, dim3((unsigned)((msg_len + 255) / 256)), dim3(256), 0, s, c.ws_e2.ptr, c.ws_dm.ptr, (uint64_t)msg_len, c.t,
-                       c.ntt->mod, c.ws_flag.ptr, c.ws_body.ptr + kn);
-    LSR_HIP(hipGetLastError());
-    unsigned long long flag = 1;
-    LSR_HIP(hipMemcpyAsync(&flag, c.ws_flag.ptr, sizeof flag, hipMemcpyDeviceToHost, s));
-    LSR_HIP(hipStreamSynchronize(s));
-    return flag == 0 ? 1 : 0;
-}
-
-// Many openings in one device pass.  results[i]: 1 / 0 / -1 exactly as the single call.
-// bodies[i] = the (k + 1) n residues u || v of opening i (already known to belong to this context); results for the
-// `live` indices only.  Bodies are gathered in pinned memory `chunk` at a time and go up in one copy.
-static void verify_bodies(const LweContext& c, const std::vector<const uint64_t*>& bodies, const std::vector<size_t>& live, const uint64_t* messages,
-                          size_t msg_len, int* results) {
-    const uint32_t n = c.n, k = c.k;
-    const size_t kn = (size_t)k * n, body_words = kn + n;
-    DeviceGuard guard(c.device);
-    std::lock_guard<std::mutex> lock(c.mutex);
-    hipStream_t s = work_stream(*c.ntt);
-    const size_t per_opening = (4 * (size_t)k + 4) * n * 8;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(live.size(), (1ull << 30) / per_opening));
-    ensure_workspace(c, chunk);
-    ensure_host_stage(c, chunk * (body_words + msg_len));
-    uint64_t* const h_bodies = c.host_stage;
-    uint64_t* const h_msgs = c.host_stage + chunk * body_words;
-    DeviceBuffer<unsigned long long> flags(chunk);
-    DeviceBuffer<uint64_t> d_msgs(chunk * msg_len), d_bodies(chunk * body_words);
-    std::vector<unsigned long long> host_flags(chunk);
-    for (size_t first = 0; first < live.size(); first += chunk) {
-        const size_t now = std::min(chunk, live.size() - first);
-        for (size_t j = 0; j < now; ++j) {
-            std::memcpy(h_bodies + j * body_words, bodies[first + j], body_words * 8);
-            std::memcpy(h_msgs + j * msg_len, messages + live[first + j] * msg_len, msg_len * 8);
-        }
-        LSR_HIP(hipMemcpyAsync(d_bodies.ptr, h_bodies, now * body_words * 8, hipMemcpyHostToDevice, s));
-        LSR_HIP(hipMemcpyAsync(d_msgs.ptr, h_msgs, now * msg_len * 8, hipMemcpyHostToDevice, s));
-        // u || v rows -> the [now][k][n] and [now][n] arrays the kernels take
-        LSR_HIP(hipMemcpy2DAsync(c.ws_u.ptr, kn * 8, d_bodies.ptr, body_words * 8, kn * 8, now, hipMemcpyDeviceToDevice, s));
-        LSR_HIP(hipMemcpy2DAsync(c.ws_v.ptr, (size_t)n * 8, d_bodies.ptr + kn, body_words * 8, (size_t)n * 8, now, hipMemcpyDeviceToDevice, s));
-        LSR_HIP(hipMemsetAsync(flags.ptr, 0, now * sizeof(unsigned long long), s));
-        launch_ntt(*c.ntt, c.ws_u.ptr, now * k, false, s);
-        launch_ntt(*c.ntt, c.ws_v.ptr, now, false, s);
-        matvec(c, c.ws_e2.ptr, c.s_hat.ptr, c.ws_u.ptr, nullptr, 1, k, 0, 1, now, s);            // <s_hat, u_hat>
-        hipLaunchKernelGGL(rsub_mod_kernel, dim3(grid_for(now * n)), dim3(256), 0, s, c.ws_e2.ptr, c.ws_v.ptr, (uint64_t)now * n, c.q);
-        launch_ntt(*c.ntt, c.ws_e2.ptr, now, true, s);
-        const uint64_t lanes = (uint64_t)now * msg_len;
-        hipLaunchKernelGGL(decode_compare_batch_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, c.ws_e2.ptr, d_msgs.ptr, (uint64_t)msg_len,
-                           (uint32_t)c.logn, (uint64_t)now, c.t, c.ntt->mod, flags.ptr);
-        LSR_HIP(hipGetLastError());
-        LSR_HIP(hipMemcpyAsync(host_flags.data(), flags.ptr, now * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        LSR_HIP(hipStreamSynchronize(s));
-        for (size_t j = 0; j < now; ++j) results[live[first + j]] = host_flags[j] == 0 ? 1 : 0;
-    }
-}
-
-// screening shared by the two batched forms: results[i] decided on the host (-1 / 0 / 1), or the opening goes to the device
-static bool screen_opening(const LweContext& c, const uint64_t* body, size_t msg_len, int* result) {
     const size_t body_words = ((size_t)c.k + 1) * c.n;
-    bool canonical = true;
-    for (size_t x = 0; x < body_words && canonical; ++x) canonical = body[x] < c.q;
-    if (!canonical) { *result = -1; return false; }
-    if (msg_len > c.n) { *result = 0; return false; }
-    if (msg_len == 0) { *result = 1; return false; }
-    return true;
+    if (msg_len == 0 || msg_len > c.n) {                                   // decided without the device
+        for (size_t i = 0; i < body_words; ++i)
+            if (body[i] >= c.q) return -1;                                  // not a canonical payload
+        return msg_len == 0 ? 1 : 0;                                        // commitment.cpp:219-221
+    }
+    DeviceGuard guard(c.device);
+    std::lock_guard<std::mutex> lock(c.mutex);
+    // a single call is launch-bound: the row goes up in one copy as it is (cm->data IS the wire row) and the canonicity screening
+    // happens on the device with everything else
+    int result = -1;
+    verify_host_rows(c, cm->data, message, msg_len, 1, &result, work_stream(*c.ntt));
+    return result;
 }
 
+// screening shared by the batched forms when the message length alone decides (0 or > n): -1 / 0 / 1 on the host
+static int screen_opening(const LweContext& c, const uint64_t* body, size_t msg_len) {
+    const size_t body_words = ((size_t)c.k + 1) * c.n;
+    for (size_t x = 0; x < body_words; ++x)
+        if (body[x] >= c.q) return -1;
+    return msg_len == 0 ? 1 : 0;
+}
+
+// Many openings in one device pass.  results[i]: 1 / 0 / -1 exactly as the single call.  The
+// commitments' words (cm->data is the wire row) are gathered in pinned memory a chunk at a time and go up in one copy.
 static void verify_opening_batch(const LweContext& c, const LweCommitment* const* cms, const uint64_t* messages, size_t msg_len, size_t count,
                                  int* results) {
+    const size_t row = kHeaderWords + ((size_t)c.k + 1) * c.n;
     std::vector<size_t> live;           // indices that reach the device
-    std::vector<const uint64_t*> bodies;
     for (size_t i = 0; i < count; ++i) {
         const uint64_t* body = nullptr;
         if (!cms[i] || !parse_commitment(c, cms[i], &body)) { results[i] = -1; continue; }
-        if (!screen_opening(c, body, msg_len, &results[i])) continue;
+        if (msg_len == 0 || msg_len > c.n) { results[i] = screen_opening(c, body, msg_len); continue; }
         live.push_back(i);
-        bodies.push_back(body);
     }
-    if (!live.empty()) verify_bodies(c, bodies, live, messages, msg_len, results);
+    if (live.empty()) return;
+    DeviceGuard guard(c.device);
+    std::lock_guard<std::mutex> lock(c.mutex);
+    hipStream_t s = work_stream(*c.ntt);
+    const size_t chunk = verify_chunk(c, live.size());
+    ensure_host_stage(c, chunk * (row + msg_len));
+    uint64_t* const h_rows = c.host_stage;
+    uint64_t* const h_msgs = c.host_stage + chunk * row;
+    std::vector<int> part(chunk);
+    for (size_t first = 0; first < live.size(); first += chunk) {
+        const size_t now = std::min(chunk, live.size() - first);
+        for (size_t j = 0; j < now; ++j) {
+            std::memcpy(h_rows + j * row, cms[live[first + j]]->data, row * 8);
+            std::memcpy(h_msgs + j * msg_len, messages + live[first + j] * msg_len, msg_len * 8);
+        }
+        verify_host_rows(c, h_rows, h_msgs, msg_len, now, part.data(), s);
+        for (size_t j = 0; j < now; ++j) results[live[first + j]] = part[j];
+    }
 }
 
 // the same for commitments stored back to back (rows of lsr_lwe_commit_batch_flat): the rows go up as they are, the header
-// and canonicity checks run on the device while the rows are split into the u and v arrays
+// and canonicity checks run on the device
 static void verify_opening_batch_flat(const LweContext& c, const uint64_t* words, const uint64_t* messages, size_t msg_len, size_t count, int* results) {
-    const uint32_t n = c.n, k = c.k;
-    const size_t kn = (size_t)k * n, row = kHeaderWords + kn + n;
-    if (msg_len == 0 || msg_len > n) {   // decided by the screening alone: host path
+    const size_t row = kHeaderWords + ((size_t)c.k + 1) * c.n;
+    if (msg_len == 0 || msg_len > c.n) {   // decided by the screening alone: host path
         for (size_t i = 0; i < count; ++i) {
             const LweCommitment view{const_cast<uint64_t*>(words + i * row), row};
             const uint64_t* body = nullptr;
-            if (!parse_commitment(c, &view, &body)) { results[i] = -1; continue; }
-            (void)screen_opening(c, body, msg_len, &results[i]);
+            results[i] = parse_commitment(c, &view, &body) ? screen_opening(c, body, msg_len) : -1;
         }
         return;
     }
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
-    hipStream_t s = work_stream(*c.ntt);
-    const size_t per_opening = (4 * (size_t)k + 5) * n * 8;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(count, (1ull << 30) / per_opening));
-    ensure_workspace(c, chunk);
-    DeviceBuffer<unsigned long long> flags(chunk);
-    DeviceBuffer<uint32_t> bad(chunk);
-    DeviceBuffer<uint64_t> d_msgs(chunk * msg_len), d_rows(chunk * row);
-    std::vector<unsigned long long> host_flags(chunk);
-    std::vector<uint32_t> host_bad(chunk);
-    for (size_t first = 0; first < count; first += chunk) {
-        const size_t now = std::min(chunk, count - first);
-        LSR_HIP(hipMemcpyAsync(d_rows.ptr, words + first * row, now * row * 8, hipMemcpyHostToDevice, s));
-        LSR_HIP(hipMemcpyAsync(d_msgs.ptr, messages + first * msg_len, now * msg_len * 8, hipMemcpyHostToDevice, s));
-        LSR_HIP(hipMemsetAsync(flags.ptr, 0, now * sizeof(unsigned long long), s));
-        LSR_HIP(hipMemsetAsync(bad.ptr, 0, now * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(unpack_commitments_kernel, dim3(grid_for(now * row)), dim3(256), 0, s, d_rows.ptr, c.ws_u.ptr, c.ws_v.ptr, bad.ptr, (uint64_t)kn,
-                           (uint64_t)n, (uint64_t)now, c.q, c.t, (uint64_t)n | ((uint64_t)k << 32));
-        launch_ntt(*c.ntt, c.ws_u.ptr, now * k, false, s);
-        launch_ntt(*c.ntt, c.ws_v.ptr, now, false, s);
-        matvec(c, c.ws_e2.ptr, c.s_hat.ptr, c.ws_u.ptr, nullptr, 1, k, 0, 1, now, s);            // <s_hat, u_hat>
-        hipLaunchKernelGGL(rsub_mod_kernel, dim3(grid_for(now * n)), dim3(256), 0, s, c.ws_e2.ptr, c.ws_v.ptr, (uint64_t)now * n, c.q);
-        launch_ntt(*c.ntt, c.ws_e2.ptr, now, true, s);
-        const uint64_t lanes = (uint64_t)now * msg_len;
-        hipLaunchKernelGGL(decode_compare_batch_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, c.ws_e2.ptr, d_msgs.ptr, (uint64_t)msg_len,
-                           (uint32_t)c.logn, (uint64_t)now, c.t, c.ntt->mod, flags.ptr);
-        LSR_HIP(hipGetLastError());
-        LSR_HIP(hipMemcpyAsync(host_flags.data(), flags.ptr, now * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        LSR_HIP(hipMemcpyAsync(host_bad.data(), bad.ptr, now * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        LSR_HIP(hipStreamSynchronize(s));
-        for (size_t j = 0; j < now; ++j) results[first + j] = host_bad[j] ? -1 : (host_flags[j] == 0 ? 1 : 0);
-    }
+    verify_host_rows(c, words, messages, msg_len, count, results, work_stream(*c.ntt));
 }
 
 static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** cms, const uint64_t* coeffs, size_t count) {
@@ -1418,7 +1457,7 @@ int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uin
         // advisor: the upload used to precede it, so the sampler of an unfused context read a freed-and-reallocated buffer)
         const bool fused = ctx->a_perm.ptr != nullptr;
         if (!fused) lsr::ensure_workspace(*ctx, batch);
-        else if (ctx->ws_keys.count < batch * 4) ctx->ws_keys.allocate(batch * 4);
+        else lsr::ensure_input_space(*ctx, batch);
         LSR_HIP(hipMemcpyAsync(ctx->ws_keys.ptr, ctx->ws_key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
         if (fused) {
             lsr::mlwe_matvec_fused(*ctx, d_r, nullptr, d_u, batch, s, ctx->ws_keys.ptr);

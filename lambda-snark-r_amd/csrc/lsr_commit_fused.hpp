@@ -186,38 +186,58 @@ __device__ __forceinline__ void f8_fill_twiddles(double* __restrict__ tw_lds, co
     for (int s = 0; s < 7; ++s) tw_lds[kF8TwShared + s * kF8Threads + t] = mine[s];
 }
 
-// a_perm[tile][i][c][kp][lane][e] = (double) a_hat[i][c][tile * 4096 + f8_base<3>(lane) + 2 kp + e]
-static __global__ void __launch_bounds__(256) f8_permute_matrix_kernel(double* __restrict__ a_perm, const uint64_t* __restrict__ a_hat, uint32_t k,
-                                                                         int logn) {
-    const uint64_t total = (uint64_t)k * k << logn;
+// last inverse round of a transform whose top index bit lies in this tile (n = 4096: the tile IS the polynomial): the stage of
+// bit 11 folds n^-1 into both outputs (SEAL's scalar path; RoundConsts), so the outputs are fresh products, |x| < q
+template <class TW>
+__device__ __forceinline__ void f8_inverse_round_final(double (&v)[kF8Regs], TW&& tw, const RoundConsts<ArithF64>& cs, const ModParams& p) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ArithF64::gs(v[2 * u], v[2 * u + 1], tw(3 + u), p);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const double w = tw(1 + u);
+#pragma unroll
+        for (int l = 0; l < 2; ++l) ArithF64::gs(v[4 * u + l], v[4 * u + l + 2], w, p);
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) ArithF64::gs_scaled(v[l], v[l + 4], cs.w_last_scaled, cs.n_inv, p);
+}
+
+// Lane-major copy of the matrix a tile pipeline multiplies by (16 B per lane, coalesced):
+//   out[tile][i][c][kp][lane][e] = (double) column(c0 + c)[i][tile * 4096 + f8_base<3>(lane) + 2 kp + e],   c < nc
+// where column x < k is A_hat[i][x] (the commitment's A^T product) and column k is `extra`[i] (b_hat for the scalar component of
+// a full commitment, s_hat for an opening).
+static __global__ void __launch_bounds__(256) f8_permute_matrix_kernel(double* __restrict__ out, const uint64_t* __restrict__ a_hat,
+                                                                         const uint64_t* __restrict__ extra, uint32_t k, uint32_t c0, uint32_t nc, int logn) {
+    const uint64_t total = (uint64_t)k * nc << logn;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += stride) {
         const uint32_t e = g & 1u, lane = (g >> 1) & 511u, kp = (g >> 10) & 3u;
-        const uint64_t rest = g >> 12;                       // (tile * k + i) * k + c
-        const uint32_t c = rest % k, i = (rest / k) % k;
-        const uint64_t tile = rest / ((uint64_t)k * k);
+        const uint64_t rest = g >> 12;                       // (tile * k + i) * nc + c
+        const uint32_t c = rest % nc, i = (rest / nc) % k;
+        const uint64_t tile = rest / ((uint64_t)k * nc);
         const uint64_t x = (tile << 12) + f8_base<3>(lane) + 2 * kp + e;
-        a_perm[g] = f64_from_u52(a_hat[(((uint64_t)i * k + c) << logn) + x]);
+        const uint32_t col = c0 + c;
+        const uint64_t word = col < k ? a_hat[(((uint64_t)i * k + col) << logn) + x] : extra[((uint64_t)i << logn) + x];
+        out[g] = f64_from_u52(word);
     }
 }
 
-// blk: the workgroup's position in the (witness vector, tile) grid — the hardware block index when the stage is a kernel of its
-// own, a number handed out by mlwe_mixed (below) when it is one role of a mixed launch
-template <int K>
-__device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_t* __restrict__ rws, uint64_t* __restrict__ u,
-                                                     const double* __restrict__ a_perm, uint32_t vectors, const ModParams& p,
-                                                     const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
-    __shared__ double tile_lds[kF8TileWords];
-    __shared__ double tw_lds[kF8TwShared + kF8TwPrivate];
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The tile pipeline: K polynomials in, NC linear combinations out, nothing but the ends touches memory.
+//   forward: for i < K: src.load(i) -> the 12 low forward stages -> acc[c] += M[i][c] o x_hat_i
+//   inverse: for c < NC: the 12 low inverse stages of acc[c] -> sink.store(c)
+// `mat` is this tile's slice of a lane-major matrix copy (f8_permute_matrix_kernel): [i][c][kp][lane][2].
+// FULL: the tile is the whole polynomial (n = 4096), so the last inverse round carries the n^-1-scaled final stage.
+// Src:  load(i, v)  — polynomial i in the layout of round 0 (register k of lane t = tile index t + 512 k), as doubles;
+//       ahead(i)    — optional hint issued three rounds before load(i + 1).
+// Sink: store(c, x) — output c in the same layout (raw elements, |x| <= q/2 + 1; FULL: |x| < q, fresh products).
+// Both may use workgroup barriers (every lane calls them, in the same order).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int K, int NC, bool FULL, class Src, class Sink>
+__device__ __forceinline__ void f8_tile_pipeline(uint32_t tile_pos, Src& src, Sink& sink, const double* __restrict__ mat, const ModParams& p,
+                                                 const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw, const RoundConsts<ArithF64>& cs,
+                                                 double* __restrict__ tile_lds, double* __restrict__ tw_lds) {
     const uint32_t t = threadIdx.x;
-    // (witness vector j, tile).  Workgroups b and b + 8 share an XCD under the observed round-robin placement (speed only):
-    // an XCD then sees 2 of the >= 16 tile positions of A_hat, which stay in its L2.
-    const int tp_log = p.logn - 12;
-    const uint32_t rest = blk >> 3;
-    const uint32_t tile = (blk & 7u) | ((rest & ((1u << (tp_log - 3)) - 1u)) << 3);
-    const uint32_t j = rest >> (tp_log - 3);
-    if (j >= vectors) return;
-    const uint32_t tile_pos = tile << 12;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane(t & ~63u);
     // per-round LDS addresses of register 0 (doubles)
     double* const row0 = tile_lds + f8_slot(f8_base<0>(t));
@@ -228,9 +248,9 @@ __device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_
     const double* const tw3 = tw_lds + kF8TwShared + t;                 // this lane's 7 multipliers, stride 512
     const uint32_t e5 = f8_base<2>(t) >> 6, e4 = f8_base<2>(t) >> 5, e3 = f8_base<2>(t) >> 4;
 
-    double acc[K][kF8Regs];
+    double acc[NC][kF8Regs];
 #pragma unroll
-    for (int c = 0; c < K; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) acc[c][k] = 0.0;
 
@@ -248,11 +268,7 @@ __device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_
 #pragma unroll 1
     for (int i = 0; i < K; ++i) {
         double v[kF8Regs];
-        {
-            const rsrc_t src = make_rsrc(rws + ((((size_t)j * K + i) << p.logn) + tile_pos), 4096u * 8u);
-#pragma unroll
-            for (int k = 0; k < kF8Regs; ++k) v[k] = __longlong_as_double((long long)buf_load64<LSR_F8_LOAD_AUX>(src, t * 8u, (uint32_t)k * 4096u));
-        }
+        src.load(i, v);
         f8_forward_round(v, tw_r0, p);
         if (i > 0) __syncthreads();                      // the previous polynomial's last LDS reads are done
 #pragma unroll
@@ -260,15 +276,7 @@ __device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) v[k] = row1[f8_slot((uint32_t)k << 6)];
-#if LSR_F8_TOUCH
-        // Pull the next polynomial's tile towards this XCD's L2 three rounds ahead of its use: one dword per 128-byte line
-        // (a real prefetch into registers would need 16 more VGPRs than the 128 that two workgroups per CU allow).
-        uint32_t touch = 0;
-        if (i + 1 < K && t < 256) {
-            const rsrc_t nxt = make_rsrc(rws + ((((size_t)j * K + i + 1) << p.logn) + tile_pos), 4096u * 8u);
-            touch = __builtin_amdgcn_raw_buffer_load_b32(nxt, (int)(t * 128u), 0, 0);
-        }
-#endif
+        const uint32_t hint = src.ahead(i);
         f8_forward_round(v, tw_r1, p);
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) row1[f8_slot((uint32_t)k << 6)] = v[k];
@@ -278,7 +286,7 @@ __device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_
         f8_forward_round(v, tw_r2, p);
 #if LSR_F8_MAT_AHEAD
         double2 a[4];
-        const rsrc_t slab = make_rsrc(a_perm + ((((size_t)tile * K + i) * K) << 12), (uint32_t)K * 4u * 512u * 16u);
+        const rsrc_t slab = make_rsrc(mat + (((size_t)i * NC) << 12), (uint32_t)NC * 4u * 512u * 16u);
         const auto fetch = [&](int c, int kp) {
             uint64_t lo, hi;
             buf_load128(slab, t * 16u, (uint32_t)(c * 4 + kp) * 8192u, lo, hi);
@@ -295,19 +303,19 @@ __device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_
         for (int k = 0; k < kF8Regs; ++k) v[k] = row3[k];
 #endif
         f8_forward_round(v, tw_r3, p);
-        // acc[c] += A_hat[i][c] o r_hat_i on this lane's 8 positions
-        [[maybe_unused]] const double* const mat = a_perm + ((((size_t)tile * K + i) * K) << 12) + (size_t)t * 2;
+        // acc[c] += M[i][c] o x_hat_i on this lane's 8 positions
+        [[maybe_unused]] const double* const mat_i = mat + (((size_t)i * NC) << 12) + (size_t)t * 2;
 #if LSR_F8_MAT_AHEAD
         {   // rolling window of four 16-byte matrix loads: each slot is refilled for the next component as soon as its two
             // products are issued, so a wave waits for L2 once per polynomial instead of once per load
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) a[kp] = fetch(0, kp);
-            static_for<0, K>([&](auto cc) {
+            static_for<0, NC>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
 #pragma unroll
                 for (int kp = 0; kp < 4; ++kp) {
                     const double2 cur = a[kp];
-                    if constexpr (c + 1 < K) a[kp] = fetch(c + 1, kp);
+                    if constexpr (c + 1 < NC) a[kp] = fetch(c + 1, kp);
                     acc[c][2 * kp] += mulmod_f64(v[2 * kp], cur.x, p.qd, p.inv_qd);
                     acc[c][2 * kp + 1] += mulmod_f64(v[2 * kp + 1], cur.y, p.qd, p.inv_qd);
                 }
@@ -315,18 +323,16 @@ __device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_
         }
 #else
 #pragma unroll
-        for (int c = 0; c < K; ++c) {
+        for (int c = 0; c < NC; ++c) {
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) {
-                const double2 a = *reinterpret_cast<const double2*>(mat + (((size_t)c * 4 + kp) << 10));
+                const double2 a = *reinterpret_cast<const double2*>(mat_i + (((size_t)c * 4 + kp) << 10));
                 acc[c][2 * kp] += mulmod_f64(v[2 * kp], a.x, p.qd, p.inv_qd);
                 acc[c][2 * kp + 1] += mulmod_f64(v[2 * kp + 1], a.y, p.qd, p.inv_qd);
             }
         }
 #endif
-#if LSR_F8_TOUCH
-        asm volatile("" ::"v"(touch));
-#endif
+        asm volatile("" ::"v"(hint));
     }
 
     // ---- inverse: each output component through the tile ------------------------------------------------------------------
@@ -335,7 +341,7 @@ __device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_
     f8_uniform_twiddles<0>(w0, inv_tw, tile_pos, p.logn);
     f8_uniform_twiddles<1>(w1, inv_tw, tile_pos + f8_base<1>(wave0), p.logn);
     __syncthreads();
-    static_for<0, K>([&](auto cc) {
+    static_for<0, NC>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         double x[kF8Regs];
 #pragma unroll
@@ -365,11 +371,79 @@ __device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) x[k] = row0[f8_slot((uint32_t)k << 9)];
-        f8_inverse_round<true>(x, tw_r0, p);              // 32 q -> q/2: what the strided round expects
-        const rsrc_t dst = make_rsrc(u + ((((size_t)j * K + c) << p.logn) + tile_pos), 4096u * 8u);
-#pragma unroll
-        for (int k = 0; k < kF8Regs; ++k) buf_store64<LSR_F8_STORE_AUX>(dst, t * 8u, (uint32_t)k * 4096u, (uint64_t)__double_as_longlong(x[k]));
+        if constexpr (FULL) f8_inverse_round_final(x, tw_r0, cs, p);   // sums up to 32 q enter the n^-1 products: |x| < q
+        else f8_inverse_round<true>(x, tw_r0, p);         // 32 q -> q/2: what the strided round expects
+        sink.store(c, x);
     });
+}
+
+// (witness vector j, tile) of workgroup `blk`.  Workgroups b and b + 8 share an XCD under the observed round-robin placement (speed
+// only): an XCD then sees 2 of the >= 16 tile positions of the matrix, which stay in its L2.  n = 4096: one tile, j = blk.
+__device__ __forceinline__ void f8_block_position(uint32_t blk, int logn, uint32_t* j, uint32_t* tile) {
+    const int tp_log = logn - 12;
+    if (tp_log < 3) { *tile = blk & ((1u << tp_log) - 1u); *j = blk >> tp_log; return; }
+    const uint32_t rest = blk >> 3;
+    *tile = (blk & 7u) | ((rest & ((1u << (tp_log - 3)) - 1u)) << 3);
+    *j = rest >> (tp_log - 3);
+}
+
+// polynomials of witness vector j as raw f64 elements (the strided round's output): polynomial i at base + (i << logn)
+struct F8RawSource {
+    const uint64_t* base;
+    int logn;
+    uint32_t tile_pos, polys;
+    __device__ __forceinline__ void load(int i, double (&v)[kF8Regs]) const {
+        const rsrc_t src = make_rsrc(base + (((size_t)i << logn) + tile_pos), 4096u * 8u);
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) v[k] = __longlong_as_double((long long)buf_load64<LSR_F8_LOAD_AUX>(src, threadIdx.x * 8u, (uint32_t)k * 4096u));
+    }
+    // Pull the next polynomial's tile towards this XCD's L2 three rounds ahead of its use: one dword per 128-byte line
+    // (a real prefetch into registers would need 16 more VGPRs than the 128 that two workgroups per CU allow).
+    __device__ __forceinline__ uint32_t ahead(int i) const {
+#if LSR_F8_TOUCH
+        if (i + 1 < (int)polys && threadIdx.x < 256) {
+            const rsrc_t nxt = make_rsrc(base + (((size_t)(i + 1) << logn) + tile_pos), 4096u * 8u);
+            return __builtin_amdgcn_raw_buffer_load_b32(nxt, (int)(threadIdx.x * 128u), 0, 0);
+        }
+#endif
+        return 0;
+    }
+};
+// component c as raw f64 elements at base + (c << logn): the inverse strided round's input
+struct F8RawSink {
+    uint64_t* base;
+    int logn;
+    uint32_t tile_pos;
+    __device__ __forceinline__ void store(int c, const double (&x)[kF8Regs]) const {
+        const rsrc_t dst = make_rsrc(base + (((size_t)c << logn) + tile_pos), 4096u * 8u);
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) buf_store64<LSR_F8_STORE_AUX>(dst, threadIdx.x * 8u, (uint32_t)k * 4096u, (uint64_t)__double_as_longlong(x[k]));
+    }
+};
+
+// Middle stage of the n = 2^16 / 2^17 pipelines: witness vector j's K polynomials at rws + j in_pitch (raw, after the forward strided
+// round) -> NC components at out + j out_pitch (raw, for the inverse strided round); mat = [tile][K][NC] lane-major slices.
+// blk: the workgroup's position in the (witness vector, tile) grid — the hardware block index when the stage is a kernel of its
+// own, a number handed out by mlwe_mixed (below) when it is one role of a mixed launch
+template <int K, int NC>
+__device__ __forceinline__ void mlwe_mid_body(uint32_t blk, const uint64_t* __restrict__ rws, size_t in_pitch, uint64_t* __restrict__ out, size_t out_pitch,
+                                              const double* __restrict__ mat, uint32_t vectors, const ModParams& p, const double* __restrict__ fwd_tw,
+                                              const double* __restrict__ inv_tw) {
+    __shared__ double tile_lds[kF8TileWords];
+    __shared__ double tw_lds[kF8TwShared + kF8TwPrivate];
+    uint32_t j, tile;
+    f8_block_position(blk, p.logn, &j, &tile);
+    if (j >= vectors) return;
+    const uint32_t tile_pos = tile << 12;
+    F8RawSource src{rws + (size_t)j * in_pitch, p.logn, tile_pos, (uint32_t)K};
+    F8RawSink sink{out + (size_t)j * out_pitch, p.logn, tile_pos};
+    f8_tile_pipeline<K, NC, false>(tile_pos, src, sink, mat + (((size_t)tile * K * NC) << 12), p, fwd_tw, inv_tw, RoundConsts<ArithF64>{}, tile_lds, tw_lds);
+}
+template <int K>
+__device__ __forceinline__ void mlwe_mid_fused8_body(uint32_t blk, const uint64_t* __restrict__ rws, uint64_t* __restrict__ u,
+                                                     const double* __restrict__ a_perm, uint32_t vectors, const ModParams& p,
+                                                     const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
+    mlwe_mid_body<K, K>(blk, rws, (size_t)K << p.logn, u, (size_t)K << p.logn, a_perm, vectors, p, fwd_tw, inv_tw);
 }
 
 template <int K>
@@ -377,6 +451,13 @@ __global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_fused8(const uint64_t*
                                                                   const double* __restrict__ a_perm, uint32_t vectors, ModParams p,
                                                                   const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
     mlwe_mid_fused8_body<K>(blockIdx.x, rws, u, a_perm, vectors, p, fwd_tw, inv_tw);
+}
+// the general form: NC components out of K polynomials, explicit pitches (full commitments write into wire rows; openings read one)
+template <int K, int NC>
+__global__ void __launch_bounds__(kF8Threads, 4) mlwe_mid_general(const uint64_t* __restrict__ rws, size_t in_pitch, uint64_t* __restrict__ out,
+                                                                   size_t out_pitch, const double* __restrict__ mat, uint32_t vectors, ModParams p,
+                                                                   const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw) {
+    mlwe_mid_body<K, NC>(blockIdx.x, rws, in_pitch, out, out_pitch, mat, vectors, p, fwd_tw, inv_tw);
 }
 
 // =================================================================================================================================

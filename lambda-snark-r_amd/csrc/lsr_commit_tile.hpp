@@ -1,0 +1,235 @@
+// Whole commitments and whole openings at the reference's ring degree, ONE workgroup each (round 3).
+//
+// Every reference caller commits with n = 4096, k = 2; a 4096-residue polynomial is exactly one tile of the fused
+// pipeline (lsr_commit_fused.hpp), so lwe_commit (cpp-core/src/commitment.cpp:138-164, contract commitment.h:43-52) is one launch:
+//     for i < k : r_i <- chi (ChaCha20 stream + CDT search, in the lanes) -> 12 forward stages in LDS
+//                 acc[c] += A_hat[i][c] o r_hat_i (c < k),  acc[k] += b_hat[i] o r_hat_i
+//     for c <= k: 12 inverse stages (n^-1 folded into the last) -> + e1_c | + e2 + Delta (m mod t) -> the wire row, canonical
+// instead of the eight launches of the unfused path (three samplers writing r, e1, e2 to memory, forward transforms, two matrix
+// products, inverse transforms, finish, pack): nothing but the finished row is written, nothing but the message is read.
+// lwe_verify_opening (commitment.cpp:200-232) is the same pipeline with the row's u as the source, s_hat as the one-column
+// matrix and a decode-and-compare sink: one launch reads the row once.
+//
+// FP64 flavour (q < 2^45), k <= 4, CDT tables of <= 64 entries (sigma <= ~6.9); other contexts use the general kernels.
+#pragma once
+
+#include "lsr_commit_fused.hpp"
+
+namespace lsr {
+
+constexpr uint32_t kRowHeaderWords = 5;                           // data[0] + 4 header words (lsr_commit.hip: the wire format)
+constexpr uint64_t kRowMagic = 0x313030304352534CULL;             // "LSRC0001"
+
+// floor((hi:lo) / q) for a dividend below 2^61 * 2^21 (quotient fits 64 bits), by Barrett + fix-up
+__device__ __forceinline__ uint64_t div128_by_q(uint64_t hi, uint64_t lo, const ModParams& p) {
+    const uint64_t c1 = __umul64hi(lo, p.barrett_lo);
+    const uint64_t m1_lo = lo * p.barrett_hi, m1_hi = __umul64hi(lo, p.barrett_hi);
+    const uint64_t m2_lo = hi * p.barrett_lo, m2_hi = __umul64hi(hi, p.barrett_lo);
+    uint64_t s = c1 + m1_lo;
+    uint64_t carry = s < c1;
+    const uint64_t s2 = s + m2_lo;
+    carry += s2 < s;
+    uint64_t quot = hi * p.barrett_hi + m1_hi + m2_hi + carry;
+    uint64_t rem = lo - quot * p.q;
+    while (rem >= p.q) { rem -= p.q; ++quot; }
+    return quot;
+}
+// round(t w / q) mod t for a canonical residue w: the plaintext slot an opening decodes (commitment.cpp:215-218 via SEAL decrypt).
+// w <= q - 1 gives a quotient <= t, so the reduction mod t is one select.
+__device__ __forceinline__ uint64_t decode_slot(uint64_t w, uint64_t t, const ModParams& p) {
+    const uint64_t lo0 = w * t, hi0 = __umul64hi(w, t);
+    const uint64_t lo = lo0 + (p.q >> 1);
+    const uint64_t hi = hi0 + (lo < lo0);
+    const uint64_t d = div128_by_q(hi, lo, p);
+    return d == t ? 0 : d;
+}
+
+// m mod t for any 64-bit word and t < 2^21, in FP64 (a 64-bit integer division costs hundreds of instructions; the message embed
+// sits in the same lanes as the transforms).  Both steps reduce a value below 2^53 with one rounded quotient, an exact FMA remainder
+// and a fix-up of at most one t either way.
+struct PlainModulus {
+    double t, inv_t;
+};
+__device__ __forceinline__ double reduce_below_2p53(double x, const PlainModulus& m) {
+    const double k = __builtin_floor(x * m.inv_t);
+    double r = __builtin_fma(-k, m.t, x);                 // |x - k t| < 2 t: exact
+    r = r < 0.0 ? r + m.t : r;
+    return r >= m.t ? r - m.t : r;
+}
+__device__ __forceinline__ double mod_plain(uint64_t word, const PlainModulus& m) {
+    const double hi = reduce_below_2p53((double)(uint32_t)(word >> 32), m);
+    return reduce_below_2p53(hi * 4294967296.0 + (double)(uint32_t)word, m);        // < 2^21 2^32 + 2^32 < 2^53
+}
+
+// One stream block (eight consecutive coefficients, block number = lane) of the Gaussian object (key, domain, index), left in `stage`
+// as signed 16-bit values in coefficient order.  Every lane of the workgroup takes part (lane table).
+__device__ __forceinline__ void f8_sample_to_stage(const uint64_t* __restrict__ key, uint32_t domain, uint32_t index, const LaneTable& tab, uint32_t entries,
+                                                   int16_t* __restrict__ stage) {
+    uint64_t w[8], u[8];
+    stream_block(key, domain, index, threadIdx.x, w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = w[i] >> 1;
+    uint32_t magnitude[8];
+    cdt_magnitudes(tab, nullptr, entries, u, magnitude);
+    uint32_t packed[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t a = magnitude[2 * i], b = magnitude[2 * i + 1];
+        const uint32_t sa = (w[2 * i] & 1ull) ? 0u - a : a, sb = (w[2 * i + 1] & 1ull) ? 0u - b : b;
+        packed[i] = (sa & 0xFFFFu) | (sb << 16);
+    }
+    *reinterpret_cast<uint4*>(stage + 8 * threadIdx.x) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+}
+
+struct CommitTileJob {
+    uint64_t* rows;              // [batch][5 + (k + 1) n] wire rows, device
+    const uint64_t* keys;        // [batch][4] per-commitment stream keys
+    const uint64_t* msgs;        // [batch][msg_len]; only read when copy > 0
+    uint64_t msg_len, copy;      // copy = min(msg_len, n) slots are embedded (commitment.cpp:146-149)
+    const uint64_t* cdf;         // CDT table (64-bit thresholds)
+    uint32_t entries;            // scanned entries (<= 64)
+    uint32_t batch;
+    uint64_t q, t, delta;
+};
+
+// r_i sampled where the forward transform wants it
+struct CommitTileSource {
+    const uint64_t* key;
+    LaneTable tab;
+    uint32_t entries;
+    int16_t* stage;
+    __device__ __forceinline__ void load(int i, double (&v)[kF8Regs]) const {
+        f8_sample_to_stage(key, kDomR, (uint32_t)i, tab, entries, stage);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) v[k] = (double)stage[threadIdx.x + 512u * (uint32_t)k];
+        // the stage is rewritten by the next load / store only after the barriers of the rounds in between
+    }
+    __device__ __forceinline__ uint32_t ahead(int) const { return 0; }
+};
+// u_c = . + e1_c,  v = . + e2 + Delta (m mod t): canonical words into the wire row
+template <int K>
+struct CommitTileSink {
+    const CommitTileJob& job;
+    const uint64_t* key;
+    LaneTable tab;
+    int16_t* stage;
+    uint64_t* row;               // this commitment's row
+    const uint64_t* msg;         // this commitment's message
+    const ModParams& p;
+    __device__ __forceinline__ void store(int c, const double (&x)[kF8Regs]) const {
+        f8_sample_to_stage(key, c < K ? kDomE1 : kDomE2, c < K ? (uint32_t)c : 0u, tab, job.entries, stage);
+        __syncthreads();
+        uint64_t* const dst = row + kRowHeaderWords + ((size_t)c << 12);
+        const PlainModulus pm{(double)job.t, 1.0 / (double)job.t};
+        const double delta = (double)job.delta;
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) {
+            const uint32_t idx = threadIdx.x + 512u * (uint32_t)k;
+            double v = x[k] + (double)stage[idx];
+            if (c == K && idx < job.copy) v += delta * mod_plain(msg[idx], pm);     // Delta (t - 1) < q: exact
+            dst[idx] = u52_from_f64(canonical_f64(v, p.qd, p.inv_qd));              // |v| < 2 q + 2^15
+        }
+    }
+};
+
+template <int K>
+__global__ void __launch_bounds__(kF8Threads, 4) commit_tile_kernel(CommitTileJob job, const double* __restrict__ ab_perm, ModParams p,
+                                                                     const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw,
+                                                                     RoundConsts<ArithF64> cs) {
+    __shared__ double tile_lds[kF8TileWords];
+    __shared__ double tw_lds[kF8TwShared + kF8TwPrivate];
+    __shared__ __attribute__((aligned(16))) int16_t stage[4096];
+    const uint32_t j = blockIdx.x;
+    if (j >= job.batch) return;
+    const uint64_t* const key = job.keys + 4 * (size_t)j;
+    const LaneTable tab = lane_table_load(job.cdf, job.entries);
+    const size_t row_words = kRowHeaderWords + ((size_t)(K + 1) << 12);
+    uint64_t* const row = job.rows + (size_t)j * row_words;
+    if (threadIdx.x < kRowHeaderWords) {
+        const uint32_t w = threadIdx.x;
+        row[w] = w == 0 ? 8ull * (row_words - 1) : (w == 1 ? kRowMagic : (w == 2 ? (4096ull | ((uint64_t)K << 32)) : (w == 3 ? job.q : job.t)));
+    }
+    CommitTileSource src{key, tab, job.entries, stage};
+    CommitTileSink<K> sink{job, key, tab, stage, row, job.msgs + (size_t)j * job.msg_len, p};
+    f8_tile_pipeline<K, K + 1, true>(0u, src, sink, ab_perm, p, fwd_tw, inv_tw, cs, tile_lds, tw_lds);
+}
+
+// ---- openings -------------------------------------------------------------------------------------------------------------------
+struct VerifyTileJob {
+    const uint64_t* rows;        // [count][5 + (k + 1) n] wire rows, device
+    const uint64_t* msgs;        // [count][msg_len] claimed messages (raw words, commitment.cpp:223-226)
+    uint64_t msg_len;            // 1 .. n
+    unsigned long long* flags;   // [count]: OR over the slots of decoded ^ claimed
+    uint32_t* bad;               // [count]: != 0 when the row is not a canonical commitment of this context
+    uint32_t count;
+    uint64_t q, t;
+};
+// u_i of the row: canonical words -> elements; a word >= q or a wrong header marks the row
+template <int K>
+struct VerifyTileSource {
+    const uint64_t* row;
+    uint32_t* bad;
+    uint64_t q;
+    __device__ __forceinline__ void load(int i, double (&v)[kF8Regs]) const {
+        const uint64_t* const src = row + kRowHeaderWords + ((size_t)i << 12);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) {
+            const uint64_t raw = src[threadIdx.x + 512u * (uint32_t)k];
+            ok = ok && raw < q;
+            v[k] = f64_from_u52(raw);
+        }
+        if (!ok) atomicOr(bad, 1u);
+    }
+    __device__ __forceinline__ uint32_t ahead(int) const { return 0; }
+};
+// w = v - INTT(<s_hat, u_hat>), decoded slot by slot and compared with the claimed words as given
+template <int K>
+struct VerifyTileSink {
+    const VerifyTileJob& job;
+    const uint64_t* row;
+    const uint64_t* msg;
+    unsigned long long* flag;
+    uint32_t* bad;
+    const ModParams& p;
+    __device__ __forceinline__ void store(int, const double (&x)[kF8Regs]) const {
+        const uint64_t* const vsrc = row + kRowHeaderWords + ((size_t)K << 12);
+        uint64_t diff = 0;
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < kF8Regs; ++k) {
+            const uint32_t idx = threadIdx.x + 512u * (uint32_t)k;
+            const uint64_t raw = vsrc[idx];
+            ok = ok && raw < job.q;
+            if (idx < job.msg_len) {
+                const uint64_t w = u52_from_f64(canonical_f64(f64_from_u52(raw) - x[k], p.qd, p.inv_qd));
+                diff |= decode_slot(w, job.t, p) ^ msg[idx];
+            }
+        }
+        if (!ok) atomicOr(bad, 1u);
+        if (diff) atomicOr(flag, (unsigned long long)diff);
+    }
+};
+
+template <int K>
+__global__ void __launch_bounds__(kF8Threads, 4) verify_tile_kernel(VerifyTileJob job, const double* __restrict__ s_perm, ModParams p,
+                                                                     const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw,
+                                                                     RoundConsts<ArithF64> cs) {
+    __shared__ double tile_lds[kF8TileWords];
+    __shared__ double tw_lds[kF8TwShared + kF8TwPrivate];
+    const uint32_t j = blockIdx.x;
+    if (j >= job.count) return;
+    const size_t row_words = kRowHeaderWords + ((size_t)(K + 1) << 12);
+    const uint64_t* const row = job.rows + (size_t)j * row_words;
+    if (threadIdx.x < kRowHeaderWords) {
+        const uint32_t w = threadIdx.x;
+        const uint64_t want = w == 0 ? 8ull * (row_words - 1) : (w == 1 ? kRowMagic : (w == 2 ? (4096ull | ((uint64_t)K << 32)) : (w == 3 ? job.q : job.t)));
+        if (row[w] != want) atomicOr(&job.bad[j], 1u);
+    }
+    VerifyTileSource<K> src{row, &job.bad[j], job.q};
+    VerifyTileSink<K> sink{job, row, job.msgs + (size_t)j * job.msg_len, &job.flags[j], &job.bad[j], p};
+    f8_tile_pipeline<K, 1, true>(0u, src, sink, s_perm, p, fwd_tw, inv_tw, cs, tile_lds, tw_lds);
+}
+
+}  // namespace lsr
