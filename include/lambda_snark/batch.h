@@ -90,6 +90,27 @@ int lsr_lwe_commit_batch_flat(LweContext* ctx, const uint64_t* messages, size_t 
 int lsr_lwe_commit_batch_flat_device(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch,
                                      const uint64_t* seeds, uint64_t* d_out_words) LSR_NOEXCEPT;
 
+/* Whole commitments without a byte of host traffic (round 3).  lsr_lwe_commit_keys derives, on the host, the per-commitment
+ * 256-bit stream keys exactly as lwe_commit does (seed != 0: PRF of seed, context id and embedded message; seed == 0: fresh OS
+ * entropy) into out_keys[batch][4]; lsr_lwe_commit_rows_device then turns DEVICE arrays d_keys[batch][4] and
+ * d_messages[batch][msg_len] into the wire rows d_rows[batch][lsr_lwe_commitment_words(ctx)] — word for word what
+ * lsr_lwe_commit_batch_flat returns for the same keys — asynchronously on `stream`.  Contexts with ring_degree 4096 (FP64
+ * flavour, rank <= 4, sigma <= ~6.9) run it as ONE launch with one workgroup per commitment: r, e1, e2 are sampled in the
+ * lanes, transformed and multiplied in LDS, and only the finished row is written; ring_degree 2^16 / 2^17 sample inside the
+ * strided transform rounds (three launches per chunk).  lsr_lwe_pipeline names the path a context takes: "tile", "fused",
+ * "fused-matvec" (only the matrix-vector workload is fused), "general".
+ * Calls on one context are ordered one behind the other (each waits for the previous call's last kernel), whatever streams the
+ * caller passes; results are ready when `stream` has drained.  0 / -1. */
+int lsr_lwe_commit_keys(const LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds,
+                        uint64_t* out_keys) LSR_NOEXCEPT;
+int lsr_lwe_commit_rows_device(LweContext* ctx, const uint64_t* d_messages, size_t msg_len, size_t batch,
+                               const uint64_t* d_keys, uint64_t* d_rows, void* stream) LSR_NOEXCEPT;
+/* `count` openings of device-resident rows against device-resident claimed messages (1 <= msg_len <= ring_degree):
+ * d_results[i] = 1 / 0 / -1 with the meaning of lwe_verify_opening.  Asynchronous on `stream`.  0 / -1. */
+int lsr_lwe_verify_rows_device(const LweContext* ctx, const uint64_t* d_rows, const uint64_t* d_messages, size_t msg_len,
+                               size_t count, int* d_results, void* stream) LSR_NOEXCEPT;
+const char* lsr_lwe_pipeline(const LweContext* ctx) LSR_NOEXCEPT;
+
 /* `count` openings in one device pass.  messages = [count][msg_len]; results[i] = 1 / 0 / -1 with the meaning of
  * lwe_verify_opening (cpp-core/src/commitment.cpp:200-232) for (commitments[i], messages[i]); NULL entries => -1.
  * Returns 0, or -1 if the call itself failed. */

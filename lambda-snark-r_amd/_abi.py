@@ -7,8 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LAMBDA_SNARK_CORE_LIB: an experiment build of the same library (csrc/Makefile VARIANT=...), for A/B measurements only
-LIB_PATH = os.environ.get("LAMBDA_SNARK_CORE_LIB") or os.path.join(_HERE, "lib", "liblambda_snark_core.so")
+# The product library, always: no environment variable redirects the loader (an experiment build of the same sources,
+# csrc/Makefile VARIANT=..., is loaded explicitly by the tool that measures it: use_library(path) before the first call).
+LIB_PATH = os.path.join(_HERE, "lib", "liblambda_snark_core.so")
 
 u64 = ctypes.c_uint64
 u32 = ctypes.c_uint32
@@ -122,6 +123,10 @@ SIGNATURES = {
     "lsr_fs_challenge_batch_flat": (c_int, [vp, c_size, vp, c_size, c_size, u64, vp, vp, ctypes.c_uint]),
     "lsr_fs_challenge_batch_device": (c_int, [vp, c_size, vp, c_size, c_size, u64, vp, vp, vp]),
     "lsr_lwe_commit_batch_flat_device": (c_int, [vp, vp, c_size, c_size, vp, vp]),
+    "lsr_lwe_commit_keys": (c_int, [vp, vp, c_size, c_size, vp, vp]),
+    "lsr_lwe_commit_rows_device": (c_int, [vp, vp, c_size, c_size, vp, vp, vp]),
+    "lsr_lwe_verify_rows_device": (c_int, [vp, vp, vp, c_size, c_size, vp, vp]),
+    "lsr_lwe_pipeline": (ctypes.c_char_p, [vp]),
     "lsr_minimal_primitive_root": (u64, [u64, u32]),
     # r1cs.h (SEAL/NTL-free shim, host only)
     "lambda_snark_r1cs_create": (c_int, [ctypes.POINTER(SparseMatrix), ctypes.POINTER(SparseMatrix), ctypes.POINTER(SparseMatrix), u64, ctypes.POINTER(vp)]),
@@ -200,6 +205,13 @@ def lib():
     global _lib
     if _lib is None:
         _lib = load_library()
+    return _lib
+
+
+def use_library(path):
+    """Development tools only: bind the package to an experiment build instead of the product library."""
+    global _lib
+    _lib = load_library(path)
     return _lib
 
 

@@ -262,6 +262,9 @@ struct LweContext {
     mutable hipStream_t side[kMaxSide] = {nullptr, nullptr};
     mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr};
     mutable int n_side = 0;
+    // asynchronous entry points share the context's workspaces and side streams: each call's stream first waits for the previous
+    // call's last kernel (recorded here), so calls on one context are ordered whatever streams the caller brings
+    mutable hipEvent_t ev_last = nullptr;
     // pipeline selection, read from the environment ONCE when the context is created (include/lambda_snark/batch.h lists the
     // variables): a context never changes the kernels that sign its commitments under the caller's feet
     struct Tuning {
@@ -467,6 +470,7 @@ static void destroy_lwe_context(LweContext* c) {
             if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         }
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        if (c->ev_last) (void)hipEventDestroy(c->ev_last);
         if (c->host_stage) (void)hipHostFree(c->host_stage);
         if (c->host_in) {
             volatile uint64_t* hi = c->host_in;
@@ -519,6 +523,15 @@ static void join_lanes(const LweContext& c, hipStream_t s, int lanes) {
         LSR_HIP(hipEventRecord(c.ev_join[i - 1], c.side[i - 1]));
         LSR_HIP(hipStreamWaitEvent(s, c.ev_join[i - 1], 0));
     }
+}
+
+// bracket of an asynchronous entry point (caller holds c.mutex): order this call behind the previous one on the same context
+static void begin_async(const LweContext& c, hipStream_t s) {
+    if (c.ev_last) LSR_HIP(hipStreamWaitEvent(s, c.ev_last, 0));
+}
+static void end_async(const LweContext& c, hipStream_t s) {
+    if (!c.ev_last) LSR_HIP(hipEventCreateWithFlags(&c.ev_last, hipEventDisableTiming));
+    LSR_HIP(hipEventRecord(c.ev_last, s));
 }
 
 // MIXED schedule of the 4 + 12 pipeline (n = 2^16, blinding residues given; caller holds c.mutex): launch t carries the
@@ -1262,6 +1275,75 @@ int lsr_lwe_commit_batch_flat_device(LweContext* ctx, const uint64_t* messages, 
     return commit_batch_flat("lsr_lwe_commit_batch_flat_device", ctx, messages, msg_len, batch, seeds, d_out_words, true);
 }
 
+int lsr_lwe_commit_keys(const LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, uint64_t* out_keys) noexcept {
+    if (!ctx || !out_keys || (!messages && msg_len)) return -1;
+    try {
+        const size_t copy = std::min<size_t>(msg_len, ctx->n);
+        for (size_t j = 0; j < batch; ++j) {
+            const lsr::StreamKey key = seeds && seeds[j] ? lsr::derive_commit_key(seeds[j], ctx->keys.id, messages + j * msg_len, copy, ctx->t) : lsr::fresh_key();
+            lsr::key_words(key, out_keys + 4 * j);
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lsr_lwe_commit_keys: ") + e.what());
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
+int lsr_lwe_commit_rows_device(LweContext* ctx, const uint64_t* d_messages, size_t msg_len, size_t batch, const uint64_t* d_keys, uint64_t* d_rows,
+                               void* stream) noexcept {
+    if (!ctx || !d_keys || !d_rows || (!d_messages && msg_len)) return -1;
+    if (batch == 0) return 0;
+    try {
+        lsr::DeviceGuard guard(ctx->device);
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        lsr::begin_async(*ctx, s);
+        lsr::commit_rows_device(*ctx, d_messages ? d_messages : d_keys, msg_len, batch, d_keys, d_rows, s);
+        lsr::end_async(*ctx, s);
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lsr_lwe_commit_rows_device: ") + e.what());
+        std::fprintf(stderr, "lwe_commit error: %s\n", e.what());
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
+int lsr_lwe_verify_rows_device(const LweContext* ctx, const uint64_t* d_rows, const uint64_t* d_messages, size_t msg_len, size_t count, int* d_results,
+                               void* stream) noexcept {
+    if (!ctx || !d_rows || !d_messages || !d_results || msg_len == 0 || msg_len > ctx->n) return -1;
+    if (count == 0) return 0;
+    try {
+        lsr::DeviceGuard guard(ctx->device);
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        lsr::begin_async(*ctx, s);
+        lsr::verify_rows_device(*ctx, d_rows, d_messages, msg_len, count, s);
+        hipLaunchKernelGGL(lsr::opening_verdict_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, ctx->ws_vflags.ptr, ctx->ws_vbad.ptr, d_results,
+                           (uint64_t)count);
+        LSR_HIP(hipGetLastError());
+        lsr::end_async(*ctx, s);
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lsr_lwe_verify_rows_device: ") + e.what());
+        std::fprintf(stderr, "lwe_verify_opening error: %s\n", e.what());
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
+const char* lsr_lwe_pipeline(const LweContext* ctx) noexcept {
+    if (!ctx) return "";
+    if (ctx->ab_perm.ptr && ctx->logn == 12) return "tile";
+    if (ctx->a_perm.ptr) return (ctx->ab_perm.ptr || ctx->b_perm.ptr) ? "fused" : "fused-matvec";
+    return "general";
+}
+
 LweCommitment* lwe_commit(LweContext* ctx, const uint64_t* message, size_t msg_len, uint64_t seed) noexcept {
     if (!ctx || !message) return nullptr;                                          // commitment.cpp:144
     LweCommitment* out = nullptr;
@@ -1446,8 +1528,10 @@ int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uin
         lsr::DeviceGuard guard(ctx->device);
         hipStream_t s = static_cast<hipStream_t>(stream);
         std::lock_guard<std::mutex> lock(ctx->mutex);
+        lsr::begin_async(*ctx, s);
         if (d_e1) {
             lsr::mlwe_matvec_device(*ctx, d_r, d_e1, d_u, batch, s, true);
+            lsr::end_async(*ctx, s);
             return 0;
         }
         // e1 sampled on the device from the per-vector raw-seed streams (domain 5), then added
@@ -1466,6 +1550,7 @@ int lsr_mlwe_matvec_batch_device(const LweContext* ctx, uint64_t* d_r, const uin
                                  ctx->cdf_entries, s);
             lsr::mlwe_matvec_device(*ctx, d_r, ctx->ws_e1.ptr, d_u, batch, s, false);
         }
+        lsr::end_async(*ctx, s);
         LSR_HIP(hipStreamSynchronize(s));   // seeds is a host array the caller may reuse
         return 0;
     } catch (const std::exception& e) {

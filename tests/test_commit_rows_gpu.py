@@ -1,0 +1,165 @@
+"""Whole commitments and whole openings on the fused pipelines (round 3): lwe_commit (cpp-core/src/commitment.cpp:138-164,
+contract include/lambda_snark/commitment.h:43-63) and lwe_verify_opening (commitment.cpp:200-232) as one workgroup per
+commitment at the reference's ring degree 4096, and inside the strided transform rounds at n = 2^16 / 2^17 — through the C-ABI,
+word for word against the CPU oracle and against the general (unfused) kernels of the same library."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEY = 0x1234ABCD
+SIGMA = 3.19
+
+
+def _pipeline(ctx):
+    return ctx._lib.lsr_lwe_pipeline(ctx.handle).decode()
+
+
+def _keys(ctx, msgs, seeds):
+    msgs = np.ascontiguousarray(msgs, dtype=np.uint64)
+    out = np.zeros((len(seeds), 4), dtype=np.uint64)
+    assert ctx._lib.lsr_lwe_commit_keys(ctx.handle, msgs.ctypes.data if msgs.size else None, msgs.shape[1], len(seeds), seeds.ctypes.data, out.ctypes.data) == 0
+    return out
+
+
+def _rows_device(ctx, msgs, keys, stream=None):
+    """rows of lsr_lwe_commit_rows_device for host arrays msgs[batch][msg_len], keys[batch][4]"""
+    import torch
+    batch, msg_len = msgs.shape
+    words = ctx._lib.lsr_lwe_commitment_words(ctx.handle)
+    d_msgs = torch.from_numpy(np.ascontiguousarray(msgs).view(np.int64)).cuda() if msg_len else None
+    d_keys = torch.from_numpy(keys.view(np.int64)).cuda()
+    d_rows = torch.zeros((batch, words), dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    assert ctx._lib.lsr_lwe_commit_rows_device(ctx.handle, d_msgs.data_ptr() if msg_len else None, msg_len, batch, d_keys.data_ptr(), d_rows.data_ptr(), s) == 0
+    torch.cuda.synchronize()
+    return d_rows
+
+
+def test_pipeline_selection(pkg, monkeypatch):
+    """Which contexts take which path; LAMBDA_SNARK_COMMIT_FUSED=0 (read once, at creation) forces the general kernels."""
+    shapes = {(4096, 2): "tile", (4096, 4): "tile", (4096, 1): "tile", (1024, 3): "general", (4096, 5): "general", (65536, 4): "fused", (65536, 2): "fused",
+              (131072, 1): "fused", (8192, 2): "general"}
+    for (n, k), want in shapes.items():
+        ctx = pkg.LweContext(pkg.Params(q=12289, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+        assert _pipeline(ctx) == want, (n, k)
+        ctx.close()
+    wide = pkg.LweContext(pkg.Params(q=1152921504606584833, n=4096, k=2, sigma=SIGMA), key_seed=KEY)     # 60-bit modulus: u64 flavour
+    assert _pipeline(wide) == "general"
+    wide.close()
+    big_sigma = pkg.LweContext(pkg.Params(q=1152921504606584833, n=4096, k=2, sigma=20.0), key_seed=KEY)
+    assert _pipeline(big_sigma) == "general"
+    big_sigma.close()
+    monkeypatch.setenv("LAMBDA_SNARK_COMMIT_FUSED", "0")
+    ctx = pkg.LweContext(pkg.Params(q=12289, n=4096, k=2, sigma=SIGMA), key_seed=KEY)
+    assert _pipeline(ctx) == "general"
+    ctx.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+def test_tile_commit_rows_equal_oracle(pkg, oracle, k):
+    """n = 4096, ranks 1-4, a ragged batch, message lengths 0 / short / n / longer than n (truncated, commitment.cpp:146-149),
+    words >= t (embedded mod t): every row of lsr_lwe_commit_rows_device == the oracle's lwe_commit words; the host-pointer forms
+    (lwe_commit, lsr_lwe_commit_batch_flat) give the same rows."""
+    q, n = 17592169062401, 4096
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+    assert _pipeline(ctx) == "tile"
+    t = ctx.plain_modulus
+    rng = np.random.default_rng(100 + k)
+    for msg_len, batch in ((5, 37), (0, 3), (n, 9), (n + 3, 4)):
+        msgs = rng.integers(0, t, size=(batch, msg_len), dtype=np.uint64)
+        if msg_len >= 5:
+            msgs[0, :3] = [2**63, t, 2**64 - 1]                                # out-of-range words are embedded mod t
+        seeds = rng.integers(1, 2**63, size=batch, dtype=np.uint64)
+        keys = _keys(ctx, msgs, seeds)
+        rows = _rows_device(ctx, msgs, keys).cpu().numpy().view(np.uint64)
+        for j in range(batch):
+            want = oracle.lwe_commit(q, n, k, SIGMA, KEY, [int(x) for x in msgs[j]], int(seeds[j]))
+            assert np.array_equal(rows[j], want), (k, msg_len, j)
+        if msg_len:
+            flat = pkg.Commitment.batch_words(ctx, msgs, seeds)
+            assert np.array_equal(flat, rows)
+    ctx.close()
+
+
+def test_tile_and_general_kernels_agree_on_a_large_batch(pkg, monkeypatch):
+    """2048 commitments at the reference's parameters (n = 4096, k = 2): the one-launch tile pipeline and the general kernels
+    (a second context of the same keys created with LAMBDA_SNARK_COMMIT_FUSED=0) produce identical rows, every word; both verify
+    them; fresh-entropy keys (seed 0) give distinct rows."""
+    import torch
+    q, n, k, batch, msg_len = 17592169062401, 4096, 2, 2048, 16
+    tile = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+    monkeypatch.setenv("LAMBDA_SNARK_COMMIT_FUSED", "0")
+    general = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+    monkeypatch.delenv("LAMBDA_SNARK_COMMIT_FUSED")
+    assert (_pipeline(tile), _pipeline(general)) == ("tile", "general")
+    rng = np.random.default_rng(7)
+    msgs = rng.integers(0, tile.plain_modulus, size=(batch, msg_len), dtype=np.uint64)
+    seeds = rng.integers(1, 2**63, size=batch, dtype=np.uint64)
+    keys = _keys(tile, msgs, seeds)
+    assert np.array_equal(keys, _keys(general, msgs, seeds))
+    rows_t = _rows_device(tile, msgs, keys)
+    rows_g = _rows_device(general, msgs, keys)
+    assert torch.equal(rows_t, rows_g)
+    # openings, device-resident: all open; a wrong word, a corrupted header, a non-canonical residue do not
+    d_msgs = torch.from_numpy(msgs.view(np.int64)).cuda()
+    res = torch.full((batch,), 7, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for ctx in (tile, general):
+        assert ctx._lib.lsr_lwe_verify_rows_device(ctx.handle, rows_t.data_ptr(), d_msgs.data_ptr(), msg_len, batch, res.data_ptr(), s) == 0
+        torch.cuda.synchronize()
+        assert int(res.sum().item()) == batch and int(res.min().item()) == 1
+    bad_rows = rows_t.clone()
+    bad_rows[4, 1] ^= 1                   # header
+    bad_rows[6, 10] = q                   # u residue out of range
+    bad_rows[8, 5 + k * n + 3] = q + 5    # v residue out of range
+    bad_rows[9, 5 + k * n + n - 1] += 1   # a changed v word that stays canonical: decodes to the same slot or not, but not a bad row
+    wrong = d_msgs.clone(); wrong[3, 0] += 1; wrong[5, msg_len - 1] ^= 1
+    want = np.ones(batch, dtype=np.int32); want[[3, 5]] = 0; want[[4, 6, 8]] = -1
+    for ctx in (tile, general):
+        res.fill_(7)
+        assert ctx._lib.lsr_lwe_verify_rows_device(ctx.handle, bad_rows.data_ptr(), wrong.data_ptr(), msg_len, batch, res.data_ptr(), s) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(res.cpu().numpy(), want)
+    # argument contract of the device forms
+    assert tile._lib.lsr_lwe_verify_rows_device(tile.handle, rows_t.data_ptr(), d_msgs.data_ptr(), 0, batch, res.data_ptr(), s) == -1
+    assert tile._lib.lsr_lwe_verify_rows_device(tile.handle, rows_t.data_ptr(), d_msgs.data_ptr(), n + 1, batch, res.data_ptr(), s) == -1
+    assert tile._lib.lsr_lwe_verify_rows_device(tile.handle, None, d_msgs.data_ptr(), msg_len, batch, res.data_ptr(), s) == -1
+    assert tile._lib.lsr_lwe_commit_rows_device(tile.handle, d_msgs.data_ptr(), msg_len, batch, None, rows_t.data_ptr(), s) == -1
+    assert tile._lib.lsr_lwe_commit_rows_device(tile.handle, d_msgs.data_ptr(), msg_len, 0, res.data_ptr(), rows_t.data_ptr(), s) == 0
+    # seed 0: fresh 256-bit keys, never the same row twice (commitment.h:52; the reference ignores the seed, commitment.cpp:142)
+    zero = np.zeros(8, dtype=np.uint64)
+    fresh = _keys(tile, msgs[:8], zero)
+    assert len({bytes(kk) for kk in fresh}) == 8
+    rows_f = _rows_device(tile, msgs[:8], fresh).cpu().numpy()
+    assert len({rows_f[j, 5:].tobytes() for j in range(8)}) == 8
+    tile.close(); general.close()
+
+
+def test_tile_openings_match_single_calls_and_oracle(pkg, oracle, lib):
+    """lwe_verify_opening / _batch / _batch_flat on the tile pipeline: 1 / 0 / -1 exactly as the oracle; partial messages, a claimed
+    word >= t that is congruent to the committed one (never opens: commitment.cpp:223-226)."""
+    q, n, k = 17592169062401, 4096, 2
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+    assert _pipeline(ctx) == "tile"
+    t = ctx.plain_modulus
+    rng = np.random.default_rng(5)
+    batch, msg_len = 21, n
+    msgs = rng.integers(0, t, size=(batch, msg_len), dtype=np.uint64)
+    seeds = rng.integers(1, 2**63, size=batch, dtype=np.uint64)
+    flat = pkg.Commitment.batch_words(ctx, msgs, seeds)
+    claims = msgs.copy()
+    claims[2, n - 1] = (claims[2, n - 1] + 1) % t          # last slot wrong
+    claims[7, 0] += t                                      # congruent mod t, but not the committed word
+    want = [1] * batch; want[2] = 0; want[7] = 0
+    assert pkg.verify_openings_words(ctx, flat, claims) == want
+    for j in (0, 2, 7, batch - 1):
+        assert oracle.lwe_verify(q, n, k, SIGMA, KEY, flat[j], [int(x) for x in claims[j]]) == want[j]
+        row = np.ascontiguousarray(flat[j])
+        as_struct = pkg._abi.LweCommitment(row.ctypes.data_as(pkg._abi.u64p), row.size)
+        assert lib.lwe_verify_opening(ctx.handle, ctypes.byref(as_struct), claims[j].ctypes.data, msg_len, None) == want[j]
+        # a prefix of the message opens as long as its own words match
+        assert lib.lwe_verify_opening(ctx.handle, ctypes.byref(as_struct), claims[j].ctypes.data, 100, None) == (0 if j == 7 else 1)
+    ctx.close()
