@@ -821,12 +821,62 @@ static void commit_rows_tile(const LweContext& c, const uint64_t* d_msgs, size_t
     }
 }
 
+// n = 2^16 / 2^17: per chunk of commitments, the top forward round with r sampled in the pass, the tile pipeline with the
+// [A^T | b_hat] product writing raw elements into the rows, the top inverse round in place with e1 / e2 / the message in the pass
+// (lsr_commit_tile.hpp); the chunks alternate between two lanes like the matrix-vector workload's three-launch schedule
+template <int K, int NC>
+static void launch_mid_general(const LweContext& c, const uint64_t* ws, size_t in_pitch, uint64_t* out, size_t out_pitch, const double* mat, size_t vectors,
+                               hipStream_t s) {
+    hipLaunchKernelGGL((mlwe_mid_general<K, NC>), dim3(static_cast<unsigned>(vectors << (c.logn - 12))), dim3(kF8Threads), 0, s, ws, in_pitch, out, out_pitch, mat,
+                       (uint32_t)vectors, c.ntt->mod, c.ntt->fwd_f64.ptr, c.ntt->inv_f64.ptr);
+    LSR_HIP(hipGetLastError());
+}
+static void commit_rows_fused(const LweContext& c, const uint64_t* d_msgs, size_t msg_len, size_t batch, const uint64_t* d_keys, uint64_t* d_rows,
+                              hipStream_t s) {
+    const uint32_t k = c.k, n = c.n;
+    const size_t vec_words = (size_t)k << c.logn, row_words = kHeaderWords + ((size_t)k + 1) * n;
+    const size_t chunk = std::max<size_t>(1, kSampledChunkBytes / (vec_words * 8));
+    const int streams = static_cast<int>(std::min<size_t>((size_t)kFusedStreams, (batch + chunk - 1) / chunk));
+    ensure_side_streams(c, streams);
+    const size_t slot_words = std::min(chunk, batch) * vec_words;
+    if (c.ws_mid.count < slot_words * streams) c.ws_mid.allocate(slot_words * streams);
+    const RoundConsts<ArithF64> cs{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64};
+    const int r = c.logn - 12, lo = 12;                                  // top R = 4 (n = 2^16) or 5 (2^17) index bits in the outer rounds
+    fork_lanes(c, s, streams);
+    size_t index = 0;
+    for (size_t first = 0; first < batch; first += chunk, ++index) {
+        const size_t now = std::min(chunk, batch - first);
+        hipStream_t st = index % streams == 0 ? s : c.side[index % streams - 1];
+        uint64_t* const ws = c.ws_mid.ptr + (index % streams) * slot_words;
+        uint64_t* const rows = d_rows + first * row_words;
+        const CommitTopJob job{rows, ws, d_keys + 4 * first, d_msgs + first * msg_len, (uint64_t)msg_len, (uint64_t)std::min<size_t>(msg_len, n), c.cdf.ptr,
+                               c.cdf_entries, (uint32_t)now, k, (uint64_t)row_words, c.q, c.t, c.delta};
+        const unsigned grid_f = static_cast<unsigned>((now * k << c.logn) >> (r + 8)), grid_i = static_cast<unsigned>((now * (k + 1) << c.logn) >> (r + 8));
+        if (r == 4) hipLaunchKernelGGL((commit_top_forward_kernel<4>), dim3(grid_f), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
+        else hipLaunchKernelGGL((commit_top_forward_kernel<5>), dim3(grid_f), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
+        uint64_t* const body = rows + kHeaderWords;
+        switch (k) {
+            case 1: launch_mid_general<1, 2>(c, ws, vec_words, body, row_words, c.ab_perm.ptr, now, st); break;
+            case 2: launch_mid_general<2, 3>(c, ws, vec_words, body, row_words, c.ab_perm.ptr, now, st); break;
+            case 3: launch_mid_general<3, 4>(c, ws, vec_words, body, row_words, c.ab_perm.ptr, now, st); break;
+            default:   // five accumulators do not fit the stage's 128 VGPRs: A^T first, then b_hat as a one-column pass over the same workspace
+                launch_mid_general<4, 4>(c, ws, vec_words, body, row_words, c.a_perm.ptr, now, st);
+                launch_mid_general<4, 1>(c, ws, vec_words, body + vec_words, row_words, c.b_perm.ptr, now, st);
+        }
+        if (r == 4) hipLaunchKernelGGL((commit_top_inverse_kernel<4>), dim3(grid_i), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->inv_f64.ptr, cs);
+        else hipLaunchKernelGGL((commit_top_inverse_kernel<5>), dim3(grid_i), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->inv_f64.ptr, cs);
+        LSR_HIP(hipGetLastError());
+    }
+    join_lanes(c, s, streams);
+}
+
 // wire rows d_rows[batch][5 + (k + 1) n] of `batch` commitments from device-resident keys and messages, enqueued on `s` (caller
 // holds c.mutex): the reference's lwe_commit (commitment.cpp:138-164) for a whole batch without a byte of host traffic
 static void commit_rows_device(const LweContext& c, const uint64_t* d_msgs, size_t msg_len, size_t batch, const uint64_t* d_keys, uint64_t* d_rows,
                                hipStream_t s) {
     if (!batch) return;
     if (c.ab_perm.ptr && c.logn == 12) commit_rows_tile(c, d_msgs, msg_len, batch, d_keys, d_rows, s);
+    else if (c.a_perm.ptr && (c.ab_perm.ptr || c.b_perm.ptr)) commit_rows_fused(c, d_msgs, msg_len, batch, d_keys, d_rows, s);
     else commit_rows_general(c, d_msgs, msg_len, batch, d_keys, d_rows, s);
 }
 
@@ -931,6 +981,34 @@ static void verify_rows_device(const LweContext& c, const uint64_t* d_rows, cons
             case 2: launch_verify_tile<2>(c, job, s); break;
             case 3: launch_verify_tile<3>(c, job, s); break;
             default: launch_verify_tile<4>(c, job, s); break;
+        }
+        return;
+    }
+    if (c.s_perm.ptr && c.a_perm.ptr) {     // n = 2^16 / 2^17: three launches per chunk, u read once, v read once (lsr_commit_tile.hpp)
+        const size_t vec_words = (size_t)k << c.logn;
+        const size_t chunk = std::max<size_t>(1, kFusedChunkBytes / (vec_words * 8));
+        const size_t slot = std::min(chunk, count);
+        if (c.ws_mid.count < slot * (vec_words + n)) c.ws_mid.allocate(slot * (vec_words + n));
+        const RoundConsts<ArithF64> cs{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64};
+        const int r = c.logn - 12, lo = 12;
+        for (size_t first = 0; first < count; first += chunk) {
+            const size_t now = std::min(chunk, count - first);
+            uint64_t* const ws = c.ws_mid.ptr;
+            uint64_t* const ws_out = c.ws_mid.ptr + slot * vec_words;
+            const VerifyTopJob job{d_rows + first * row, ws, ws_out, d_msgs + first * msg_len, (uint64_t)msg_len, (uint64_t)row, c.ws_vflags.ptr + first,
+                                   c.ws_vbad.ptr + first, (uint32_t)now, k, c.q, c.t};
+            const unsigned grid_f = static_cast<unsigned>((now * k << c.logn) >> (r + 8)), grid_i = static_cast<unsigned>((now << c.logn) >> (r + 8));
+            if (r == 4) hipLaunchKernelGGL((verify_top_forward_kernel<4>), dim3(grid_f), dim3(256), 0, s, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
+            else hipLaunchKernelGGL((verify_top_forward_kernel<5>), dim3(grid_f), dim3(256), 0, s, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
+            switch (k) {
+                case 1: launch_mid_general<1, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, s); break;
+                case 2: launch_mid_general<2, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, s); break;
+                case 3: launch_mid_general<3, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, s); break;
+                default: launch_mid_general<4, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, s); break;
+            }
+            if (r == 4) hipLaunchKernelGGL((verify_top_inverse_kernel<4>), dim3(grid_i), dim3(256), 0, s, job, lo, c.ntt->mod, c.ntt->inv_f64.ptr, cs);
+            else hipLaunchKernelGGL((verify_top_inverse_kernel<5>), dim3(grid_i), dim3(256), 0, s, job, lo, c.ntt->mod, c.ntt->inv_f64.ptr, cs);
+            LSR_HIP(hipGetLastError());
         }
         return;
     }

@@ -232,4 +232,208 @@ __global__ void __launch_bounds__(kF8Threads, 4) verify_tile_kernel(VerifyTileJo
     f8_tile_pipeline<K, 1, true>(0u, src, sink, s_perm, p, fwd_tw, inv_tw, cs, tile_lds, tw_lds);
 }
 
+// =================================================================================================================================
+// The same two operations at n = 2^16 / 2^17 (a polynomial is 16 / 32 tiles): three launches per chunk of commitments,
+//     commit_top_forward  — r_i SAMPLED where the top forward round wants its operands (no array of r exists), raw elements out
+//     mlwe_mid_general    — tile pipeline: 12 forward stages, [A^T | b_hat] product, 12 inverse stages, into the wire rows (raw)
+//     commit_top_inverse  — top inverse round in place on the rows, + e1_c / + e2 + Delta (m mod t) sampled in the pass, canonical
+// (rank 4: the scalar component is a second, one-column pass of the middle stage — five accumulators do not fit its 128 VGPRs).
+// A workgroup of the outer rounds owns 256 columns x 2^R rows of one polynomial = 2^R * 32 stream blocks of 8 consecutive
+// coefficients, 2^R / 8 per lane; the samples change hands through an int16 tile in LDS.
+// =================================================================================================================================
+template <int R>
+__device__ __forceinline__ void top_round_sample(int16_t* __restrict__ tile, const uint64_t* __restrict__ key, uint32_t domain, uint32_t index, int lo,
+                                                 uint32_t low0, const LaneTable& tab, uint32_t entries) {
+    constexpr int N = 1 << R;
+#pragma unroll 1
+    for (int h = 0; h < N / 8; ++h) {
+        const uint32_t b = (uint32_t)h * 256u + threadIdx.x, row = b >> 5, cb = b & 31u;
+        uint64_t w[8], u[8];
+        stream_block(key, domain, index, (((row << lo) + low0) >> 3) + cb, w);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = w[i] >> 1;
+        uint32_t magnitude[8];
+        cdt_magnitudes(tab, nullptr, entries, u, magnitude);
+        uint32_t packed[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t a = magnitude[2 * i], bb = magnitude[2 * i + 1];
+            const uint32_t sa = (w[2 * i] & 1ull) ? 0u - a : a, sb = (w[2 * i + 1] & 1ull) ? 0u - bb : bb;
+            packed[i] = (sa & 0xFFFFu) | (sb << 16);
+        }
+        *reinterpret_cast<uint4*>(tile + row * 256u + cb * 8u) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    }
+}
+// the top R forward stages on 2^R registers (table entries 1 .. 2^R - 1: the same for every lane of every polynomial)
+template <int R>
+__device__ __forceinline__ void top_round_forward(double (&v)[1 << R], const double* __restrict__ tw, const ModParams& p) {
+#pragma unroll
+    for (int j = R - 1; j >= 0; --j) {
+        const int half = 1 << j;
+#pragma unroll
+        for (int u = 0; u < (1 << (R - 1 - j)); ++u) {
+            const double w = tw[(1 << (R - 1 - j)) + u];
+#pragma unroll
+            for (int l = 0; l < half; ++l) ArithF64::ct(v[(u << (j + 1)) | l], v[((u << (j + 1)) | l) + half], w, p);
+        }
+    }
+}
+// the top R inverse stages, n^-1 folded into the last: outputs are fresh products, |v| < q
+template <int R>
+__device__ __forceinline__ void top_round_inverse(double (&v)[1 << R], const double* __restrict__ tw, const RoundConsts<ArithF64>& cs, const ModParams& p) {
+#pragma unroll
+    for (int j = 0; j < R - 1; ++j) {
+        const int half = 1 << j;
+#pragma unroll
+        for (int u = 0; u < (1 << (R - 1 - j)); ++u) {
+            const double w = tw[(1 << (R - 1 - j)) + u];
+#pragma unroll
+            for (int l = 0; l < half; ++l) ArithF64::gs(v[(u << (j + 1)) | l], v[((u << (j + 1)) | l) + half], w, p);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < (1 << (R - 1)); ++l) ArithF64::gs_scaled(v[l], v[l + (1 << (R - 1))], cs.w_last_scaled, cs.n_inv, p);
+}
+
+struct CommitTopJob {
+    uint64_t* rows;              // [vectors][row_words]
+    uint64_t* ws;                // [vectors][k][n] raw elements between the forward round and the middle stage
+    const uint64_t* keys;        // [vectors][4]
+    const uint64_t* msgs;        // [vectors][msg_len]
+    uint64_t msg_len, copy;
+    const uint64_t* cdf;
+    uint32_t entries, vectors, k;
+    uint64_t row_words;
+    uint64_t q, t, delta;
+};
+
+template <int R>
+__global__ void __launch_bounds__(256) commit_top_forward_kernel(CommitTopJob job, int lo, ModParams p, const double* __restrict__ tw) {
+    constexpr int N = 1 << R;
+    __shared__ __attribute__((aligned(16))) int16_t tile[N * 256];
+    const size_t g0 = (size_t)blockIdx.x * 256u;
+    const uint32_t poly = (uint32_t)(g0 >> lo), low0 = (uint32_t)(g0 & (((size_t)1 << lo) - 1));
+    if (poly >= job.vectors * job.k) return;
+    const uint32_t j = poly / job.k, i = poly - j * job.k;
+    const LaneTable tab = lane_table_load(job.cdf, job.entries);
+    top_round_sample<R>(tile, job.keys + 4 * (size_t)j, kDomR, i, lo, low0, tab, job.entries);
+    __syncthreads();
+    double v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = (double)tile[k * 256 + threadIdx.x];
+    top_round_forward<R>(v, tw, p);
+    uint64_t* const dst = job.ws + ((size_t)poly << (lo + R)) + low0 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < N; ++k) dst[(size_t)k << lo] = (uint64_t)__double_as_longlong(v[k]);
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) commit_top_inverse_kernel(CommitTopJob job, int lo, ModParams p, const double* __restrict__ tw, RoundConsts<ArithF64> cs) {
+    constexpr int N = 1 << R;
+    __shared__ __attribute__((aligned(16))) int16_t tile[N * 256];
+    const size_t g0 = (size_t)blockIdx.x * 256u;
+    const uint32_t poly = (uint32_t)(g0 >> lo), low0 = (uint32_t)(g0 & (((size_t)1 << lo) - 1));
+    const uint32_t comps = job.k + 1;
+    if (poly >= job.vectors * comps) return;
+    const uint32_t j = poly / comps, c = poly - j * comps;
+    uint64_t* const row = job.rows + (size_t)j * job.row_words;
+    uint64_t* const data = row + kRowHeaderWords + ((size_t)c << (lo + R)) + low0 + threadIdx.x;
+    double v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = __longlong_as_double((long long)__builtin_nontemporal_load(data + ((size_t)k << lo)));   // in flight under the cipher
+    const LaneTable tab = lane_table_load(job.cdf, job.entries);
+    const bool scalar = c == job.k;                                    // v = . + e2 + Delta (m mod t); the others u_c = . + e1_c
+    top_round_sample<R>(tile, job.keys + 4 * (size_t)j, scalar ? kDomE2 : kDomE1, scalar ? 0u : c, lo, low0, tab, job.entries);
+    __syncthreads();
+    top_round_inverse<R>(v, tw, cs, p);
+    const PlainModulus pm{(double)job.t, 1.0 / (double)job.t};
+    const double delta = (double)job.delta;
+    const uint64_t* const msg = job.msgs + (size_t)j * job.msg_len;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const uint32_t x = ((uint32_t)k << lo) + low0 + threadIdx.x;
+        double out = v[k] + (double)tile[k * 256 + threadIdx.x];
+        if (scalar && x < job.copy) out += delta * mod_plain(msg[x], pm);
+        __builtin_nontemporal_store(u52_from_f64(canonical_f64(out, p.qd, p.inv_qd)), data + ((size_t)k << lo));
+    }
+    if (c == 0 && low0 == 0 && threadIdx.x < kRowHeaderWords) {
+        const uint32_t w = threadIdx.x;
+        const uint64_t n = 1ull << (lo + R);
+        row[w] = w == 0 ? 8ull * (job.row_words - 1) : (w == 1 ? kRowMagic : (w == 2 ? (n | ((uint64_t)job.k << 32)) : (w == 3 ? job.q : job.t)));
+    }
+}
+
+// ---- openings at n = 2^16 / 2^17: top forward round straight from the rows (with the header and canonicity screening), the one-column
+// middle stage with s_hat, top inverse round into the decode-and-compare ----
+struct VerifyTopJob {
+    const uint64_t* rows;        // [count][row_words]
+    uint64_t* ws;                // [count][k][n] raw: forward round -> middle stage
+    uint64_t* ws_out;            // [count][n] raw: middle stage -> inverse round
+    const uint64_t* msgs;
+    uint64_t msg_len, row_words;
+    unsigned long long* flags;
+    uint32_t* bad;
+    uint32_t count, k;
+    uint64_t q, t;
+};
+template <int R>
+__global__ void __launch_bounds__(256) verify_top_forward_kernel(VerifyTopJob job, int lo, ModParams p, const double* __restrict__ tw) {
+    constexpr int N = 1 << R;
+    const size_t g0 = (size_t)blockIdx.x * 256u;
+    const uint32_t poly = (uint32_t)(g0 >> lo), low0 = (uint32_t)(g0 & (((size_t)1 << lo) - 1));
+    if (poly >= job.count * job.k) return;
+    const uint32_t j = poly / job.k, i = poly - j * job.k;
+    const uint64_t* const row = job.rows + (size_t)j * job.row_words;
+    const uint64_t* const src = row + kRowHeaderWords + ((size_t)i << (lo + R)) + low0 + threadIdx.x;
+    double v[N];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const uint64_t raw = __builtin_nontemporal_load(src + ((size_t)k << lo));
+        ok = ok && raw < job.q;
+        v[k] = f64_from_u52(raw);
+    }
+    if (i == 0 && low0 == 0 && threadIdx.x < kRowHeaderWords) {
+        const uint32_t w = threadIdx.x;
+        const uint64_t n = 1ull << (lo + R);
+        const uint64_t want = w == 0 ? 8ull * (job.row_words - 1) : (w == 1 ? kRowMagic : (w == 2 ? (n | ((uint64_t)job.k << 32)) : (w == 3 ? job.q : job.t)));
+        ok = ok && row[w] == want;
+    }
+    if (!ok) atomicOr(&job.bad[j], 1u);
+    top_round_forward<R>(v, tw, p);
+    uint64_t* const dst = job.ws + ((size_t)poly << (lo + R)) + low0 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < N; ++k) dst[(size_t)k << lo] = (uint64_t)__double_as_longlong(v[k]);
+}
+template <int R>
+__global__ void __launch_bounds__(256) verify_top_inverse_kernel(VerifyTopJob job, int lo, ModParams p, const double* __restrict__ tw, RoundConsts<ArithF64> cs) {
+    constexpr int N = 1 << R;
+    const size_t g0 = (size_t)blockIdx.x * 256u;
+    const uint32_t j = (uint32_t)(g0 >> lo), low0 = (uint32_t)(g0 & (((size_t)1 << lo) - 1));
+    if (j >= job.count) return;
+    const uint64_t* const data = job.ws_out + ((size_t)j << (lo + R)) + low0 + threadIdx.x;
+    const uint64_t* const vsrc = job.rows + (size_t)j * job.row_words + kRowHeaderWords + ((size_t)job.k << (lo + R)) + low0 + threadIdx.x;
+    const uint64_t* const msg = job.msgs + (size_t)j * job.msg_len;
+    double v[N];
+    uint64_t vraw[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = __longlong_as_double((long long)__builtin_nontemporal_load(data + ((size_t)k << lo)));
+#pragma unroll
+    for (int k = 0; k < N; ++k) vraw[k] = __builtin_nontemporal_load(vsrc + ((size_t)k << lo));
+    top_round_inverse<R>(v, tw, cs, p);
+    uint64_t diff = 0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const uint32_t x = ((uint32_t)k << lo) + low0 + threadIdx.x;
+        ok = ok && vraw[k] < job.q;
+        if (x < job.msg_len) {
+            const uint64_t w = u52_from_f64(canonical_f64(f64_from_u52(vraw[k]) - v[k], p.qd, p.inv_qd));
+            diff |= decode_slot(w, job.t, p) ^ msg[x];
+        }
+    }
+    if (!ok) atomicOr(&job.bad[j], 1u);
+    if (diff) atomicOr(&job.flags[j], (unsigned long long)diff);
+}
+
 }  // namespace lsr
