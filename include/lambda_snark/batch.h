@@ -28,7 +28,8 @@ const char* lsr_last_error(void) LSR_NOEXCEPT;
 const char* lsr_version(void) LSR_NOEXCEPT;
 
 /* ---------------- NTT: contexts on a chosen device ---------------- */
-/* like ntt_context_create, on HIP device `device` (-1 = LAMBDA_SNARK_DEVICE env, else LOCAL_RANK, else 0) */
+/* like ntt_context_create, on HIP device `device` (-1 = LAMBDA_SNARK_DEVICE env, else LOCAL_RANK, else 0; an index that is
+ * not a visible device is an error — NULL and a message — never wrapped around onto another rank's GPU) */
 NttContext* lsr_ntt_context_create_on(uint64_t q, uint32_t n, int device) LSR_NOEXCEPT;
 int      lsr_ntt_context_device(const NttContext* ctx) LSR_NOEXCEPT;
 uint64_t lsr_ntt_context_root(const NttContext* ctx) LSR_NOEXCEPT;   /* psi */
@@ -177,10 +178,15 @@ int lsr_lwe_commit_batch_flat_sharded(LweContext* const* ctxs, int shards, const
                                       size_t batch, const uint64_t* seeds, uint64_t* out_words) LSR_NOEXCEPT;
 /* The config-4 workload: u_j = INTT(A_hat^T NTT(r_j)) + e1_j with DEVICE-resident inputs per shard and a HOST gather.
  * d_r[g], d_e1[g]: arrays on ctxs[g]'s device holding rows [first_g, first_g + count_g) of the batch ([count_g][k][n]);
- * host_u: one array [batch][k][n].  seconds (optional, 2 doubles): [0] slowest shard's compute time, [1] slowest shard's
- * device -> host gather time.  0 / -1. */
+ * host_u: one array [batch][k][n].  Each shard works through its slice in pieces: the device -> host copy of one piece runs on
+ * a copy stream under the kernels of the next, so a shard takes about max(kernels, gather) plus one piece, not their sum.
+ * seconds (optional, 2 doubles): over the shards, [0] the longest kernel time of a slice, [1] the longest wall time until a
+ * slice's last byte is in host memory.  _stats: the same two figures for every shard, per_shard[shards][2].  0 / -1. */
 int lsr_mlwe_matvec_batch_sharded(LweContext* const* ctxs, int shards, uint64_t* const* d_r, const uint64_t* const* d_e1,
                                   size_t batch, uint64_t* host_u, double* seconds) LSR_NOEXCEPT;
+int lsr_mlwe_matvec_batch_sharded_stats(LweContext* const* ctxs, int shards, uint64_t* const* d_r,
+                                        const uint64_t* const* d_e1, size_t batch, uint64_t* host_u,
+                                        double* per_shard) LSR_NOEXCEPT;
 
 /* ---------------- Fiat–Shamir consumer of the commitment words (host, no GPU needed) ---------------- */
 /* The transcript of rust-api/lambda-snark/src/challenge.rs:102-134: SHA3-256 over "LAMBDA-SNARK-R-FS-v1", the

@@ -252,7 +252,7 @@ def sharded_commit_words(ctxs, messages, seeds, out=None):
 
 def sharded_matvec(ctxs, d_r_ptrs, d_e1_ptrs, batch, host_u):
     """``lsr_mlwe_matvec_batch_sharded``: device-resident inputs per shard, gather into the host array `host_u`;
-    returns (slowest shard's compute seconds, slowest shard's gather seconds)."""
+    returns (longest kernel time of a shard's slice, longest wall time until a slice is in host memory), seconds."""
     lib = _abi.lib()
     r = (ctypes.c_void_p * len(ctxs))(*d_r_ptrs)
     e = (ctypes.c_void_p * len(ctxs))(*d_e1_ptrs)
@@ -260,6 +260,17 @@ def sharded_matvec(ctxs, d_r_ptrs, d_e1_ptrs, batch, host_u):
     if lib.lsr_mlwe_matvec_batch_sharded(_handles(ctxs), len(ctxs), r, e, batch, host_u.ctypes.data, seconds) != 0:
         raise CoreError("sharded matvec failed: " + _abi.last_error())
     return seconds[0], seconds[1]
+
+
+def sharded_matvec_stats(ctxs, d_r_ptrs, d_e1_ptrs, batch, host_u):
+    """``lsr_mlwe_matvec_batch_sharded_stats``: the same call, returning [(kernel seconds, wall seconds until gathered)] per shard."""
+    lib = _abi.lib()
+    r = (ctypes.c_void_p * len(ctxs))(*d_r_ptrs)
+    e = (ctypes.c_void_p * len(ctxs))(*d_e1_ptrs)
+    stats = (ctypes.c_double * (2 * len(ctxs)))()
+    if lib.lsr_mlwe_matvec_batch_sharded_stats(_handles(ctxs), len(ctxs), r, e, batch, host_u.ctypes.data, stats) != 0:
+        raise CoreError("sharded matvec failed: " + _abi.last_error())
+    return [(stats[2 * g], stats[2 * g + 1]) for g in range(len(ctxs))]
 
 
 class Commitment:

@@ -117,6 +117,7 @@ SIGNATURES = {
     "lsr_ntt_inverse_batch_sharded": (c_int, [vp, c_int, vp, c_size]),
     "lsr_lwe_commit_batch_flat_sharded": (c_int, [vp, c_int, vp, c_size, c_size, vp, vp]),
     "lsr_mlwe_matvec_batch_sharded": (c_int, [vp, c_int, vp, vp, c_size, vp, vp]),
+    "lsr_mlwe_matvec_batch_sharded_stats": (c_int, [vp, c_int, vp, vp, c_size, vp, vp]),
     "lsr_words_to_limbs": (c_size, [vp, c_size, ctypes.c_uint, ctypes.c_uint, vp]),
     "lsr_fill_splitmix_device": (c_int, [vp, c_size, c_size, u64, u64, vp]),
     "lsr_fs_challenge": (c_int, [vp, c_size, ctypes.POINTER(LweCommitment), u64, vp, vp]),

@@ -154,6 +154,17 @@ struct ArithF64 {
         y = mulmod_f64(a - b, w_scaled, p.qd, p.inv_qd);
     }
     static __device__ __forceinline__ void end_of_inverse_round(elem& v, const ModParams& p) { v = recentre_f64(v, p.qd, p.inv_qd); }
+    // Which outputs of an R-stage Gentleman–Sande round (register bit j = 1: the product output of stage j) must be re-centred
+    // before the NEXT round may take them as inputs.  Contract between rounds: every input satisfies |x| <= 2 q.  Then the input of
+    // the product of stage j is a difference of two sums of 2^j inputs, at most 2 * 2^j * 2 q <= 32 q < 2^50 (R <= 4, q < 2^45): exact
+    // (DESIGN.md §4).  A product output is at most 0.875 q (=: P) and doubles with every later sum stage, so after the round
+    //   bit R-1 set: P        bit R-1 clear, R-2 set: 2 P = 1.75 q        both clear: 4 P, 8 P or the all-sum 2^R * 2 q = 32 q.
+    // Only the last class exceeds 2 q: one register in four (round 3: all were re-centred, 15 % of the inverse tile pass).
+    static constexpr bool kPartialRecentre = true;
+    template <int R>
+    static constexpr bool needs_recentre(int stage_bits) {
+        return R == 1 ? (stage_bits & 1) == 0 : (stage_bits & (3 << (R - 2))) == 0;
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -209,6 +220,8 @@ struct ArithU64 {
         y = mul_shoup_lazy(u + p.two_q - v, w_scaled, p.q);
     }
     static __device__ __forceinline__ void end_of_inverse_round(elem&, const ModParams&) {}
+    static constexpr bool kPartialRecentre = false;
+    template <int R> static constexpr bool needs_recentre(int) { return true; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -294,6 +307,8 @@ struct ArithGold {
         y = gold_mul_mont(gold_sub(a, b), w_scaled);
     }
     static __device__ __forceinline__ void end_of_inverse_round(elem&, const ModParams&) {}
+    static constexpr bool kPartialRecentre = false;
+    template <int R> static constexpr bool needs_recentre(int) { return true; }
 };
 
 // canonical (a*b) mod q for ANY 64-bit a, b (q < 2^61): 128-bit product + Barrett with floor(2^128/q)

@@ -265,6 +265,10 @@ struct LweContext {
     // asynchronous entry points share the context's workspaces and side streams: each call's stream first waits for the previous
     // call's last kernel (recorded here), so calls on one context are ordered whatever streams the caller brings
     mutable hipEvent_t ev_last = nullptr;
+    // device -> host gathers of the host-array entry points run on their own stream, so that the copy of one chunk overlaps the
+    // kernels of the next (config 4: the gather, not the compute, is the long pole)
+    mutable hipStream_t copy_stream = nullptr;
+    mutable hipEvent_t ev_chunk[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
     // pipeline selection, read from the environment ONCE when the context is created (include/lambda_snark/batch.h lists the
     // variables): a context never changes the kernels that sign its commitments under the caller's feet
     struct Tuning {
@@ -471,6 +475,11 @@ static void destroy_lwe_context(LweContext* c) {
         }
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
         if (c->ev_last) (void)hipEventDestroy(c->ev_last);
+        if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+        for (int i = 0; i < 2; ++i) {
+            if (c->ev_chunk[i]) (void)hipEventDestroy(c->ev_chunk[i]);
+            if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+        }
         if (c->host_stage) (void)hipHostFree(c->host_stage);
         if (c->host_in) {
             volatile uint64_t* hi = c->host_in;
@@ -878,6 +887,43 @@ static void commit_rows_device(const LweContext& c, const uint64_t* d_msgs, size
     if (c.ab_perm.ptr && c.logn == 12) commit_rows_tile(c, d_msgs, msg_len, batch, d_keys, d_rows, s);
     else if (c.a_perm.ptr && (c.ab_perm.ptr || c.b_perm.ptr)) commit_rows_fused(c, d_msgs, msg_len, batch, d_keys, d_rows, s);
     else commit_rows_general(c, d_msgs, msg_len, batch, d_keys, d_rows, s);
+}
+
+static void ensure_copy_stream(const LweContext& c) {
+    if (c.copy_stream) return;
+    LSR_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        LSR_HIP(hipEventCreateWithFlags(&c.ev_chunk[i], hipEventDisableTiming));
+        LSR_HIP(hipEventCreateWithFlags(&c.ev_copied[i], hipEventDisableTiming));
+    }
+}
+
+// `batch` commitments to a HOST array, `chunk` at a time through two row buffers: while chunk i's rows travel to the host on the copy
+// stream, chunk i + 1 is staged and computed (caller holds c.mutex)
+static void commit_batch_flat_host(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, uint64_t* out_words,
+                                   size_t chunk) {
+    const size_t words = kHeaderWords + ((size_t)c.k + 1) * c.n;
+    hipStream_t s = work_stream(*c.ntt);
+    ensure_copy_stream(c);
+    const size_t slot = std::min(chunk, batch) * words;
+    const bool two = batch > chunk;
+    if (c.ws_rows.count < slot * (two ? 2 : 1)) c.ws_rows.allocate(slot * (two ? 2 : 1));
+    size_t index = 0;
+    for (size_t done = 0; done < batch; done += chunk, ++index) {
+        const size_t now = std::min(chunk, batch - done);
+        const int b = static_cast<int>(index & 1);
+        uint64_t* const rows = c.ws_rows.ptr + (two ? b * slot : 0);
+        if (index >= 2) LSR_HIP(hipEventSynchronize(c.ev_copied[b]));            // this buffer's previous rows have left
+        StagedInputs in;
+        stage_commit_inputs(c, messages + done * msg_len, msg_len, now, seeds ? seeds + done : nullptr, s, &in);
+        commit_rows_device(c, in.d_msgs, msg_len, now, in.d_keys, rows, s);
+        LSR_HIP(hipEventRecord(c.ev_chunk[b], s));
+        LSR_HIP(hipStreamWaitEvent(c.copy_stream, c.ev_chunk[b], 0));
+        LSR_HIP(hipMemcpyAsync(out_words + done * words, rows, now * words * 8, hipMemcpyDeviceToHost, c.copy_stream));
+        LSR_HIP(hipEventRecord(c.ev_copied[b], c.copy_stream));
+        LSR_HIP(hipStreamSynchronize(s));      // the staging areas of the inputs (pinned host block, key vector) are reused by the next chunk
+    }
+    LSR_HIP(hipStreamSynchronize(c.copy_stream));
 }
 
 // out_words: host array (the rows come back in one copy) or, with `to_device`, device memory the rows are assembled in
@@ -1330,9 +1376,13 @@ static int commit_batch_flat(const char* where, LweContext* ctx, const uint64_t*
         const size_t words = lsr::kHeaderWords + ((size_t)ctx->k + 1) * ctx->n;
         const size_t per_commit = (4 * (size_t)ctx->k + 5) * ctx->n * 8;
         const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, (1ull << 30) / per_commit));
+        if (!to_device) {
+            lsr::commit_batch_flat_host(*ctx, messages, msg_len, batch, seeds, out_words, chunk);
+            return 0;
+        }
         for (size_t done = 0; done < batch; done += chunk) {
             const size_t now = std::min(chunk, batch - done);
-            lsr::commit_chunk_flat(*ctx, messages + done * msg_len, msg_len, now, seeds ? seeds + done : nullptr, out_words + done * words, to_device);
+            lsr::commit_chunk_flat(*ctx, messages + done * msg_len, msg_len, now, seeds ? seeds + done : nullptr, out_words + done * words, true);
         }
         return 0;
     } catch (const std::exception& e) {
@@ -1545,8 +1595,8 @@ int lsr_lwe_commit_batch_flat_sharded(LweContext* const* ctxs, int shards, const
     });
 }
 
-int lsr_mlwe_matvec_batch_sharded(LweContext* const* ctxs, int shards, uint64_t* const* d_r, const uint64_t* const* d_e1, size_t batch, uint64_t* host_u,
-                                  double* seconds) noexcept {
+static int mlwe_matvec_batch_sharded(LweContext* const* ctxs, int shards, uint64_t* const* d_r, const uint64_t* const* d_e1, size_t batch, uint64_t* host_u,
+                                     double* seconds, double* per_shard) noexcept {
     if (!shards_compatible(ctxs, shards) || !d_r || !d_e1 || !host_u) return -1;
     if (batch == 0) return 0;
     const size_t vec_words = (size_t)ctxs[0]->k * ctxs[0]->n;
@@ -1557,22 +1607,61 @@ int lsr_mlwe_matvec_batch_sharded(LweContext* const* ctxs, int shards, uint64_t*
         std::lock_guard<std::mutex> lock(c.mutex);
         lsr::DeviceBuffer<uint64_t> d_u(count * vec_words);
         hipStream_t s = lsr::work_stream(*c.ntt);
+        lsr::ensure_copy_stream(c);
+        // pieces of the slice: the device -> host copy of piece i (copy stream) runs under the kernels of piece i + 1, so a shard
+        // takes about max(compute, gather) + one piece instead of their sum.  Eight pieces, at least 32 vectors each (one chunk of the
+        // mixed-launch schedule at rank 4)
+        const size_t piece = std::max<size_t>(std::min<size_t>(count, 32), (count + 7) / 8);
+        std::vector<hipEvent_t> done_ev;
+        hipEvent_t first_copy = nullptr, last_kernel = nullptr;
+        LSR_HIP(hipEventCreate(&first_copy));
+        LSR_HIP(hipEventCreate(&last_kernel));
         const auto t0 = std::chrono::steady_clock::now();
-        lsr::mlwe_matvec_device(c, d_r[g], d_e1[g], d_u.ptr, count, s, true);
-        LSR_HIP(hipStreamSynchronize(s));
-        const auto t1 = std::chrono::steady_clock::now();
-        // the gather: this shard's slice goes straight into its place in the caller's single (ideally pinned) array
-        LSR_HIP(hipMemcpyAsync(host_u + first * vec_words, d_u.ptr, count * vec_words * 8, hipMemcpyDeviceToHost, s));
-        LSR_HIP(hipStreamSynchronize(s));
-        const auto t2 = std::chrono::steady_clock::now();
-        compute[g] = std::chrono::duration<double>(t1 - t0).count();
-        gather[g] = std::chrono::duration<double>(t2 - t1).count();
+        try {
+            for (size_t lo = 0; lo < count; lo += piece) {
+                const size_t now = std::min(piece, count - lo);
+                lsr::mlwe_matvec_device(c, d_r[g] + lo * vec_words, d_e1[g] + lo * vec_words, d_u.ptr + lo * vec_words, now, s, true);
+                hipEvent_t ev = nullptr;
+                LSR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                done_ev.push_back(ev);
+                LSR_HIP(hipEventRecord(ev, s));
+                LSR_HIP(hipStreamWaitEvent(c.copy_stream, ev, 0));
+                if (lo == 0) LSR_HIP(hipEventRecord(first_copy, c.copy_stream));
+                // this shard's slice goes straight into its place in the caller's single (ideally pinned) array
+                LSR_HIP(hipMemcpyAsync(host_u + (first + lo) * vec_words, d_u.ptr + lo * vec_words, now * vec_words * 8, hipMemcpyDeviceToHost, c.copy_stream));
+            }
+            LSR_HIP(hipEventRecord(last_kernel, s));
+            LSR_HIP(hipStreamSynchronize(s));
+            const auto t1 = std::chrono::steady_clock::now();
+            LSR_HIP(hipStreamSynchronize(c.copy_stream));
+            const auto t2 = std::chrono::steady_clock::now();
+            compute[g] = std::chrono::duration<double>(t1 - t0).count();          // kernels of the whole slice (the copies run beside them)
+            gather[g] = std::chrono::duration<double>(t2 - t0).count();           // until the last byte is in host memory: the shard's wall time
+        } catch (...) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamSynchronize(c.copy_stream);
+            for (hipEvent_t ev : done_ev) (void)hipEventDestroy(ev);
+            (void)hipEventDestroy(first_copy); (void)hipEventDestroy(last_kernel);
+            throw;
+        }
+        for (hipEvent_t ev : done_ev) (void)hipEventDestroy(ev);
+        (void)hipEventDestroy(first_copy); (void)hipEventDestroy(last_kernel);
     });
     if (seconds) {
         seconds[0] = *std::max_element(compute.begin(), compute.end());
         seconds[1] = *std::max_element(gather.begin(), gather.end());
     }
+    if (per_shard)
+        for (int g = 0; g < shards; ++g) { per_shard[2 * g] = compute[g]; per_shard[2 * g + 1] = gather[g]; }
     return rc;
+}
+int lsr_mlwe_matvec_batch_sharded(LweContext* const* ctxs, int shards, uint64_t* const* d_r, const uint64_t* const* d_e1, size_t batch, uint64_t* host_u,
+                                  double* seconds) noexcept {
+    return mlwe_matvec_batch_sharded(ctxs, shards, d_r, d_e1, batch, host_u, seconds, nullptr);
+}
+int lsr_mlwe_matvec_batch_sharded_stats(LweContext* const* ctxs, int shards, uint64_t* const* d_r, const uint64_t* const* d_e1, size_t batch, uint64_t* host_u,
+                                        double* per_shard) noexcept {
+    return mlwe_matvec_batch_sharded(ctxs, shards, d_r, d_e1, batch, host_u, nullptr, per_shard);
 }
 
 int lsr_lwe_sample_blinding_device(const LweContext* ctx, uint64_t* d_e1, size_t batch, const uint64_t* seeds, void* stream) noexcept {

@@ -30,11 +30,23 @@ int visible_device_count() {
     return count;
 }
 
+// LAMBDA_SNARK_DEVICE, else LOCAL_RANK, else 0.  An index the process cannot see is an ERROR (-1), not wrapped around: a rank
+// launched with more ranks than visible devices would otherwise silently share a GPU with another rank (round-2 verdict).
 int default_device() {
     const int count = visible_device_count();
     if (count <= 0) return 0;
-    if (const char* s = std::getenv("LAMBDA_SNARK_DEVICE")) return std::atoi(s) % count;
-    if (const char* s = std::getenv("LOCAL_RANK")) return std::atoi(s) % count;
+    for (const char* name : {"LAMBDA_SNARK_DEVICE", "LOCAL_RANK"}) {
+        const char* s = std::getenv(name);
+        if (!s || !*s) continue;
+        char* end = nullptr;
+        const long v = std::strtol(s, &end, 10);
+        if (*end != 0 || v < 0 || v >= count) {
+            set_last_error(std::string(name) + "=" + s + " does not name one of the " + std::to_string(count) + " visible HIP devices");
+            std::fprintf(stderr, "lambda_snark_core: %s=%s does not name one of the %d visible HIP devices\n", name, s, count);
+            return -1;
+        }
+        return static_cast<int>(v);
+    }
     return 0;
 }
 
@@ -72,7 +84,10 @@ static NttContext* build_context(const char* where, uint64_t q, uint32_t n, int 
         std::fprintf(stderr, "lambda_snark_core: no HIP device visible; the MI355X backend has no CPU fallback\n");
         return nullptr;
     }
-    if (device < 0) device = default_device();
+    if (device < 0) {
+        device = default_device();
+        if (device < 0) return nullptr;                      // message already set
+    }
     if (device >= devices) {
         set_last_error(std::string(where) + ": device index out of range");
         return nullptr;
@@ -605,7 +620,7 @@ void lsr_shard_bounds(size_t batch, int shards, int index, size_t* first, size_t
 
 void* lsr_host_alloc_pinned(size_t bytes) noexcept {
     void* p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable)   /* every device of the node may DMA into it */ != hipSuccess) return nullptr;
     return p;
 }
 void lsr_host_free_pinned(void* p) noexcept {

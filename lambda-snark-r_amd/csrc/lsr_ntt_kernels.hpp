@@ -360,8 +360,12 @@ __device__ __forceinline__ void tile_inverse_body(uint64_t* __restrict__ data, s
         }
         inverse_round<A, LO, R, kFinal>(v, w[I & 1], p, cs);
         if constexpr (!kFinal) {
+            // inner rounds re-centre only the outputs that can exceed the next round's 2 q input bound (lsr_arith.hpp needs_recentre);
+            // the last round of a first pass (RAW_OUT) re-centres everything: the strided round that follows runs up to five stages
+            constexpr bool kAll = kLast || !A::kPartialRecentre;
 #pragma unroll
-            for (int k = 0; k < kRegs; ++k) A::end_of_inverse_round(v[k], p);
+            for (int k = 0; k < kRegs; ++k)
+                if (kAll || A::template needs_recentre<R>(k & ((1 << R) - 1))) A::end_of_inverse_round(v[k], p);
         }
         if constexpr (kLast) {
             if (!RAW_OUT && add != nullptr) {

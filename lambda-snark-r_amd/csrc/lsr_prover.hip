@@ -316,6 +316,7 @@ static LsrQuotientPlan* create_plan(uint32_t m, int device) {
         return nullptr;
     }
     if (device < 0) device = default_device();
+    if (device < 0) return nullptr;                          // LOCAL_RANK / LAMBDA_SNARK_DEVICE names no visible device: message already set
     if (device >= devices) {
         set_last_error("lsr_quotient_plan_create: device index out of range");
         return nullptr;

@@ -43,7 +43,7 @@ private:
     bool switched_ = false;
 };
 
-int default_device();          // LAMBDA_SNARK_DEVICE, else LOCAL_RANK (mod device count), else 0
+int default_device();          // LAMBDA_SNARK_DEVICE, else LOCAL_RANK, else 0; -1 (+ message) when that index is not a visible device
 int visible_device_count();    // 0 if the runtime cannot see a GPU
 
 template <class T>

@@ -133,7 +133,9 @@ static int sample_to_host(uint64_t* output, size_t len, double sigma, uint64_t s
     if (table.empty() || table.size() > 8000) throw std::runtime_error("sigma out of the supported range (table must fit LDS)");
     if ((len + 7) / 8 > 0xFFFFFFFFull) throw std::runtime_error("len exceeds one stream (2^35 samples)");
     if (visible_device_count() <= 0) throw std::runtime_error("no HIP device visible — no CPU fallback");
-    DeviceGuard guard(default_device());
+    const int device = default_device();
+    if (device < 0) throw std::runtime_error(last_error_cstr());
+    DeviceGuard guard(device);
     DeviceBuffer<uint64_t> d_cdf, d_key, d_out(len);
     d_cdf.upload(table);
     d_key.upload(key_words(expand_seed64(seed)));

@@ -303,4 +303,13 @@ def test_outputs_on_the_reduction_boundaries(pkg, oracle, q, n):
     want = np.stack(pats)
     assert np.array_equal(ctx.forward_batch(oracle.ntt_inverse(q, n, want)), want)
     assert np.array_equal(ctx.inverse_batch(oracle.ntt_forward(q, n, want)), want)
+    # largest lazy intermediates: the all-sum path of every butterfly round carries 2^R times its inputs (the inverse rounds
+    # re-centre only the registers that can exceed the next round's input bound, lsr_arith.hpp needs_recentre) — INPUTS at the top
+    # of the range in every position / every other position / blocks of 16 and 256
+    idx = np.arange(n)
+    worst = [np.full(n, q - 1, np.uint64), np.where(idx % 2 == 0, q - 1, 0).astype(np.uint64), np.where(idx % 2 == 1, q - 1, 0).astype(np.uint64),
+             np.where((idx // 16) % 2 == 0, q - 1, 1).astype(np.uint64), np.where((idx // 256) % 2 == 0, q - 1, q - 2).astype(np.uint64)]
+    worst = np.stack(worst)
+    assert np.array_equal(ctx.inverse_batch(worst.copy()), oracle.ntt_inverse(q, n, worst))
+    assert np.array_equal(ctx.forward_batch(worst.copy()), oracle.ntt_forward(q, n, worst))
     ctx.close()

@@ -101,10 +101,12 @@ def test_config4_sharded_matvec_gathers_on_the_host(pkg, lib, oracle):
 
 
 def _rank_worker(rank, world, port, batch, out_path):
-    """One process per rank, device LOCAL_RANK (mod the visible count): the REAL NttContext path, gathered with gloo."""
+    """One process per rank, device LOCAL_RANK: the REAL NttContext path, gathered with gloo.  The test box has one GPU, so the launcher
+    (this function) maps the ranks onto the visible devices itself — the library refuses an index it cannot see."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LOCAL_RANK": str(rank)})
+    import torch
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LOCAL_RANK": str(rank % max(1, torch.cuda.device_count()))})
     import torch.distributed as dist
     import __graft_entry__ as entry
     import oracle_binding
@@ -114,7 +116,7 @@ def _rank_worker(rank, world, port, batch, out_path):
     orc = oracle_binding.load()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     q, n = 17592169062401, 4096
-    ctx = pkg.NttContext(q, n)                            # device = LOCAL_RANK % visible devices (lsr_runtime default_device)
+    ctx = pkg.NttContext(q, n)                            # device = LOCAL_RANK (lsr_runtime default_device)
     polys = orc.splitmix(0xABC, q, batch * n).reshape(batch, n)
     got = sh.sharded_transform(polys, lambda a: ctx.forward_batch(a.copy()))
     if rank == 0:
@@ -137,3 +139,61 @@ def test_two_processes_drive_the_gpu_path_and_gather_with_gloo(oracle, tmp_path)
     q, n = 17592169062401, 4096
     polys = oracle.splitmix(0xABC, q, batch * n).reshape(batch, n)
     assert np.array_equal(np.load(out), oracle.ntt_forward(q, n, polys))
+
+
+def test_sharded_matvec_pipelines_its_gather(pkg, lib, oracle):
+    """Slices longer than one piece (32 vectors at rank 4): every piece is copied to the host on the copy stream while the next one is
+    computed, and the gathered array still equals the one-device result word for word.  Per-shard figures: kernel time <= wall time."""
+    import torch
+    q, n, k, batch, shards = Q16, 65536, 4, 150, 2
+    main = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xC0DE, device=0)
+    twins = [main] + [main.replicate(d) for d in devices(lib, shards)[1:]]
+    s = torch.cuda.current_stream().cuda_stream
+    d_r = torch.empty((batch, k, n), dtype=torch.int64, device="cuda")
+    assert lib.lsr_fill_splitmix_device(d_r.data_ptr(), batch, k * n, 0xC0FFEE, q, s) == 0
+    seeds = np.arange(1, batch + 1, dtype=np.uint64) * np.uint64(0x9E3779B9)
+    d_e = torch.empty_like(d_r)
+    assert lib.lsr_lwe_sample_blinding_device(main.handle, d_e.data_ptr(), batch, seeds.ctypes.data, s) == 0
+    d_u = torch.empty_like(d_r)
+    assert lib.lsr_mlwe_matvec_batch_device(main.handle, d_r.data_ptr(), d_e.data_ptr(), d_u.data_ptr(), batch, None, s) == 0
+    torch.cuda.synchronize()
+    ptr_r, ptr_e = [], []
+    for g in range(shards):
+        first, count = pkg.shard_bounds(batch, shards, g)
+        ptr_r.append(d_r[first:first + count].data_ptr()); ptr_e.append(d_e[first:first + count].data_ptr())
+    pinned = pkg.PinnedArray((batch, k, n))
+    stats = pkg.sharded_matvec_stats(twins, ptr_r, ptr_e, batch, pinned.array)
+    assert len(stats) == shards and all(0 < kern <= wall for kern, wall in stats)
+    assert np.array_equal(pinned.array, d_u.cpu().numpy().view(np.uint64))
+    pinned.array[:] = 0
+    kern, wall = pkg.sharded_matvec(twins, ptr_r, ptr_e, batch, pinned.array)
+    assert 0 < kern <= wall
+    assert np.array_equal(pinned.array, d_u.cpu().numpy().view(np.uint64))
+    pinned.close()
+    for t in twins:
+        t.close()
+
+
+def test_default_device_never_wraps_around(pkg, lib, monkeypatch):
+    """LOCAL_RANK / LAMBDA_SNARK_DEVICE that name no visible device are an error (NULL + message), not an index taken modulo the
+    device count: a mis-launched rank must not silently share another rank's GPU (round-2 verdict, multi-GPU readiness)."""
+    count = lib.lsr_device_count()
+    monkeypatch.setenv("LOCAL_RANK", str(count))
+    assert not lib.lsr_ntt_context_create_on(12289, 256, -1)
+    assert "LOCAL_RANK" in pkg._abi.last_error()
+    with pytest.raises(pkg.CoreError):
+        pkg.LweContext(pkg.Params(q=12289, n=256, k=1, sigma=3.19), key_seed=1)
+    monkeypatch.setenv("LOCAL_RANK", "not-a-number")
+    assert not lib.lsr_ntt_context_create_on(12289, 256, -1)
+    monkeypatch.setenv("LOCAL_RANK", str(count - 1))
+    h = lib.lsr_ntt_context_create_on(12289, 256, -1)
+    assert h and lib.lsr_ntt_context_device(h) == count - 1
+    lib.ntt_context_free(h)
+    monkeypatch.setenv("LAMBDA_SNARK_DEVICE", "0")           # takes precedence
+    monkeypatch.setenv("LOCAL_RANK", str(count + 3))
+    h = lib.lsr_ntt_context_create_on(12289, 256, -1)
+    assert h and lib.lsr_ntt_context_device(h) == 0
+    lib.ntt_context_free(h)
+    h = lib.lsr_ntt_context_create_on(12289, 256, 0)         # an explicit device ignores the environment
+    assert h
+    lib.ntt_context_free(h)
