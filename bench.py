@@ -122,14 +122,25 @@ def latest_profile_json(pattern):
         return json.load(f)
 
 
-def measured_traffic_per_forward_transform():
-    """HBM-side bytes per forward transform from the committed PMC passes of the latest round (profiles/), or None."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_inputs.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        return json.load(f).get("forward_bytes_per_transform")
+def provenance_module():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import provenance
+    finally:
+        sys.path.pop(0)
+    return provenance
+
+
+def pmc_profile(pattern):
+    """The newest committed PMC artefact profiles/<pattern> — but only if it was measured on THIS library's sources
+    (tools/provenance.py stamp): PMC counters need rocprofv3, so the run cannot collect them itself; a figure from another build
+    is reported as null, never silently."""
+    prof = latest_profile_json(pattern)
+    if prof is None:
+        return None, "no profile"
+    if not provenance_module().matches(prof):
+        return None, "profile was measured on other sources than the running library"
+    return prof, "profile matches the running library's sources"
 
 
 def main():
@@ -280,10 +291,12 @@ def main():
         commit_bytes = 3 * k * N * 8      # read r + read e1 + write u (6 291 456 B at k = 4)
         commits_per_s = world * args.commits * csteps / c_el
         per_gpu = commits_per_s / world
-        pmc = latest_profile_json("r*_pmc_commit_traffic.json") or {}
+        pmc, pmc_note = pmc_profile("r*_pmc_commit_traffic.json")
+        pmc = pmc or {}
         commit_roofline = {"bound": "hbm", "achieved": per_gpu * commit_bytes / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": per_gpu * commit_bytes / (HBM_PEAK_GBS * 1e9),
                            "traffic": (pmc.get("bytes_per_commit") or 0) * args.commits or None,
+                           "traffic_source": pmc_note,
                            "algorithmic_bytes": commit_bytes * args.commits, "launch_ms": float(np.median(c_times)) * 1e3,
                            "kernel": pmc.get("kernel", "lsr_mlwe_matvec_batch_device launch sequence (DESIGN.md §5)")}
         extra.update({"commits_per_s": commits_per_s, "commit_rank": k, "commits_per_gpu": args.commits,
@@ -333,6 +346,51 @@ def main():
                       # algorithmic bytes: read a, b, c evaluations, write the quotient (4 m words per instance)
                       "quotient_roofline_frac": qb * qm * 32 / t_q / (HBM_PEAK_GBS * 1e9)})
         plan.close(); field.close()
+
+    # ---- whole commitments and openings, device-resident (keys, messages and wire rows in HBM; HIP events on the launch stream):
+    #      lwe_commit / lwe_verify_opening for a batch (cpp-core/src/commitment.cpp:138-164,200-232) at the reference's parameters
+    #      (n = 4096, k = 2: one launch, one workgroup per commitment) and at config 3's shape (n = 2^16, k = 4: sampled inside the
+    #      strided rounds).  Algorithmic bytes per commitment = the wire row ((k + 1) n + 5 words), written once / read once. ----
+    if not args.no_commit and rank == 0:
+        torch.cuda.empty_cache()
+        full = {}
+        for label, fq, fn_, fk, fb in (("n4096_k2", 17592169062401, 4096, 2, 16384), ("n65536_k4", Q16, N, 4, 1024)):
+            fctx = pkg.LweContext(pkg.Params(q=fq, n=fn_, k=fk, sigma=3.19), key_seed=0xC0DE + 3, device=local)
+            words = lib.lsr_lwe_commitment_words(fctx.handle)
+            msg_len = 16
+            rng = np.random.default_rng(3)
+            fmsgs = rng.integers(0, fctx.plain_modulus, size=(fb, msg_len), dtype=np.uint64)
+            fseeds = rng.integers(1, 2**63, size=fb, dtype=np.uint64)
+            fkeys = np.zeros((fb, 4), dtype=np.uint64)
+            t0 = time.perf_counter()
+            assert lib.lsr_lwe_commit_keys(fctx.handle, fmsgs.ctypes.data, msg_len, fb, fseeds.ctypes.data, fkeys.ctypes.data) == 0
+            t_keys = time.perf_counter() - t0
+            d_msgs = torch.from_numpy(fmsgs.view(np.int64)).cuda()
+            d_keys = torch.from_numpy(fkeys.view(np.int64)).cuda()
+            d_rows = torch.empty((fb, words), dtype=torch.int64, device="cuda")
+            d_res = torch.zeros(fb, dtype=torch.int32, device="cuda")
+            do_commit = lambda: lib.lsr_lwe_commit_rows_device(fctx.handle, d_msgs.data_ptr(), msg_len, fb, d_keys.data_ptr(), d_rows.data_ptr(), stream)
+            do_verify = lambda: lib.lsr_lwe_verify_rows_device(fctx.handle, d_rows.data_ptr(), d_msgs.data_ptr(), msg_len, fb, d_res.data_ptr(), stream)
+            assert do_commit() == 0 and do_verify() == 0
+            t_c = event_time(do_commit, max(3, reps // 2))
+            t_v = event_time(do_verify, max(3, reps // 2))
+            torch.cuda.synchronize()
+            row_bytes = words * 8
+            full[label] = {"pipeline": lib.lsr_lwe_pipeline(fctx.handle).decode(), "batch": fb, "row_bytes": row_bytes,
+                           "commits_per_s": fb / t_c, "commit_ms_per_batch": t_c * 1e3, "commit_roofline_frac": fb * row_bytes / t_c / (HBM_PEAK_GBS * 1e9),
+                           "openings_per_s": fb / t_v, "verify_ms_per_batch": t_v * 1e3, "verify_roofline_frac": fb * row_bytes / t_v / (HBM_PEAK_GBS * 1e9),
+                           "all_rows_open": bool((d_res == 1).all().item()),
+                           "host_key_derivation_commits_per_s": fb / t_keys}
+            # the oracle's words for two of the timed rows (outside the timed region)
+            if not args.no_cpu and world == 1:
+                orc = entry.load_oracle()
+                host_rows = d_rows[[0, fb - 1]].cpu().numpy().view(np.uint64)
+                ok = all(np.array_equal(host_rows[i], orc.lwe_commit(fq, fn_, fk, 3.19, 0xC0DE + 3, [int(x) for x in fmsgs[j]], int(fseeds[j])))
+                         for i, j in enumerate((0, fb - 1)))
+                full[label]["rows_match_cpu_oracle"] = bool(ok)
+            fctx.close()
+            del d_rows, d_msgs, d_keys, d_res
+        extra["full_commit"] = full
 
     # ---- complete commitments at the reference's parameters (n = 4096, k = 2), PCIe included: host-visible throughput of the
     #      additive flat entry points (never the headline value) ----
@@ -399,16 +457,20 @@ def main():
         pinned = pkg.PinnedArray((total, k, N))
         ptr_r, ptr_e = [p.data_ptr() for p in parts_r], [p.data_ptr() for p in parts_e]
         pkg.sharded_matvec(twins, ptr_r, ptr_e, total, pinned.array)              # warm-up (workspaces, pinned pages)
-        walls, comp, gath = [], [], []
+        walls, stats = [], []
         for _ in range(3):
             t0 = time.perf_counter()
-            c_s, g_s = pkg.sharded_matvec(twins, ptr_r, ptr_e, total, pinned.array)
-            walls.append(time.perf_counter() - t0); comp.append(c_s); gath.append(g_s)
+            st = pkg.sharded_matvec_stats(twins, ptr_r, ptr_e, total, pinned.array)
+            walls.append(time.perf_counter() - t0); stats.append(st)
         w = float(np.median(walls))
-        result = {"devices": n_dev, "commits": total, "commits_per_s_with_host_gather": total / w,
-                  "compute_ms_slowest_shard": float(np.median(comp)) * 1e3, "gather_ms_slowest_shard": float(np.median(gath)) * 1e3,
-                  "gather_GBps": total * k * N * 8 / float(np.median(gath)) / 1e9 if np.median(gath) > 0 else None,
-                  "note": "lsr_mlwe_matvec_batch_sharded: device-resident r and e1 per shard, u gathered into one pinned host array"}
+        mid = stats[int(np.argsort(walls)[len(walls) // 2])]          # the per-shard figures of the median run
+        result = {"devices": n_dev, "commits": total, "commits_per_s_with_host_gather": total / w, "wall_ms": w * 1e3,
+                  "kernel_ms_slowest_shard": max(kk for kk, _ in mid) * 1e3, "wall_ms_slowest_shard": max(ww for _, ww in mid) * 1e3,
+                  "per_device": [{"device": g, "vectors": pkg.shard_bounds(total, n_dev, g)[1], "kernel_ms": kk * 1e3, "wall_ms_until_gathered": ww * 1e3,
+                                  "gather_GBps": pkg.shard_bounds(total, n_dev, g)[1] * k * N * 8 / ww / 1e9 if ww > 0 else None}
+                                 for g, (kk, ww) in enumerate(mid)],
+                  "note": "lsr_mlwe_matvec_batch_sharded_stats: device-resident r and e1 per shard; every shard copies one piece of its slice "
+                          "to the pinned host array while it computes the next, so its wall time is about max(kernels, gather) + one piece"}
         pinned.close()
         for tctx in twins:
             tctx.close()
@@ -425,6 +487,8 @@ def main():
         cpu_barrier()
 
     if rank == 0:
+        ntt_pmc, ntt_pmc_note = pmc_profile("r*_roofline_inputs.json")
+        extra["provenance"] = provenance_module().provenance()
         transforms = 2 * args.polys * args.steps * world
         value = transforms / elapsed
         achieved = fwd_rate * NTT_BYTES / 1e9
@@ -439,7 +503,8 @@ def main():
             # achieved = ALGORITHMIC bytes (1 MiB per transform) / measured time of one forward batch launch sequence
             # (8 chunks x {ntt_strided_round<4>, ntt_tile_forward<12>}); traffic = PMC bytes of the same sequence.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (measured_traffic_per_forward_transform() or 0) * args.polys or None,
+                         "traffic": ((ntt_pmc or {}).get("forward_bytes_per_transform") or 0) * args.polys or None,
+                         "traffic_source": ntt_pmc_note,
                          "algorithmic_bytes": NTT_BYTES * args.polys, "launch_ms": t_fwd * 1e3,
                          "kernel": "forward NTT batch = ntt_strided_round<ArithF64,4> + ntt_tile_forward<ArithF64,12> per 512-poly chunk",
                          # what two passes over the array can reach on this part: every residue crosses the L2 <-> memory fabric

@@ -1377,7 +1377,15 @@ static int commit_batch_flat(const char* where, LweContext* ctx, const uint64_t*
         const size_t per_commit = (4 * (size_t)ctx->k + 5) * ctx->n * 8;
         const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, (1ull << 30) / per_commit));
         if (!to_device) {
-            lsr::commit_batch_flat_host(*ctx, messages, msg_len, batch, seeds, out_words, chunk);
+            // host array: pieces of about 32 MiB of rows, so that the copy of one piece (57 GB/s over PCIe: the long pole) runs under
+            // the staging and the kernels of the next
+            // (page-locked destinations only: a copy into pageable memory is staged synchronously by the runtime and overlaps nothing,
+            // so there the rows travel in one large copy as before)
+            hipPointerAttribute_t attr{};
+            const bool pinned = hipPointerGetAttributes(&attr, out_words) == hipSuccess && attr.type == hipMemoryTypeHost;
+            (void)hipGetLastError();
+            const size_t piece = pinned ? std::max<size_t>(1, std::min<size_t>(chunk, (size_t(32) << 20) / (words * 8))) : chunk;
+            lsr::commit_batch_flat_host(*ctx, messages, msg_len, batch, seeds, out_words, piece);
             return 0;
         }
         for (size_t done = 0; done < batch; done += chunk) {
