@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) add_mod_kernel(uint64_t* __restrict__ dst
     }
 }
 
-// v[j][x] = (v[j][x] + e2[j][x] + delta * (msg[j][x] mod t)) mod q for x < copy, the message term absent beyond:
+// v[j][x] = (v[j][x] + e2[j][x] + round(q (msg[j][x] mod t) / t)) mod q for x < copy, the message term absent beyond:
 // the scalar component's epilogue (e2 blinding + message embedding, commitment.cpp:146-152 truncation/padding)
 __global__ void __launch_bounds__(256) finish_v_kernel(uint64_t* __restrict__ v, const uint64_t* __restrict__ e2, const uint64_t* __restrict__ msgs,
                                                          uint64_t msg_len, uint64_t copy, uint32_t logn, uint64_t count, uint64_t delta, uint64_t t,
@@ -158,7 +158,9 @@ __global__ void __launch_bounds__(256) finish_v_kernel(uint64_t* __restrict__ v,
         uint64_t s = v[i] + e2[i];
         if (s >= q) s -= q;
         if (x < copy) {
-            s += delta * (msgs[j * msg_len + x] % t);   // delta * (t-1) < q
+            // round(q m' / t) = delta m' + floor((rho m' + t/2) / t), m' = m mod t (lsr_commit_tile.hpp embed_plain; any q < 2^61 here)
+            const uint64_t mm = msgs[j * msg_len + x] % t;
+            s += delta * mm + ((q - delta * t) * mm + (t >> 1)) / t;   // < q
             if (s >= q) s -= q;
         }
         v[i] = s;
@@ -1190,14 +1192,23 @@ static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** 
     // The reference's 72-bit SEAL modulus absorbs any c_i < t (commitment.cpp:88-96,247-266); a 44-bit modulus does not, and a
     // commitment that cannot open is refused here rather than returned.  A 60-bit NTT prime as params->modulus gives the
     // reference's range.
+    // Coefficients act through their CENTRED representative mod t (round-2 advisor): c in (t/2, t) is the small negative number
+    // c - t, multiplied in as the residue q - (t - c), so subtracting a commitment (coefficient t - 1) costs one unit of noise.
+    auto centred = [&](uint64_t coeff, uint64_t* residue) {
+        const uint64_t cf = coeff % c.t;
+        const bool negative = cf > c.t / 2;
+        *residue = negative ? c.q - (c.t - cf) : cf;
+        return static_cast<double>(negative ? c.t - cf : cf);
+    };
     double weight = 0;
     for (size_t i = 0; i < count; ++i)
-        if (cms[i]) weight += static_cast<double>(coeffs[i] % c.t);
-    if (weight * c.noise_unit >= 0.5 * static_cast<double>(c.delta)) {
-        set_last_error("lwe_linear_combine: coefficients exceed the noise budget of this context's modulus (sum of c_i mod t too large); "
+        if (cms[i]) { uint64_t unused; weight += centred(coeffs[i], &unused); }
+    // + 1: the rounding of the scaled messages (at most 1/2 per commitment, times its coefficient)
+    if (weight * (c.noise_unit + 1.0) >= 0.5 * static_cast<double>(c.delta)) {
+        set_last_error("lwe_linear_combine: coefficients exceed the noise budget of this context's modulus (sum of |c_i|, c_i centred mod t, too large); "
                        "create the context with a wider NTT prime as modulus");
         std::fprintf(stderr, "lwe_linear_combine error: sum of coefficients %.0f exceeds the noise budget %.0f of the %d-bit modulus\n", weight,
-                     0.5 * static_cast<double>(c.delta) / c.noise_unit, 64 - __builtin_clzll(c.q));
+                     0.5 * static_cast<double>(c.delta) / (c.noise_unit + 1.0), 64 - __builtin_clzll(c.q));
         return nullptr;
     }
     bool any = false;
@@ -1220,7 +1231,7 @@ static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** 
             return nullptr;                                                // commitment.cpp:253-255
         }
         std::memcpy(h_terms + staged * body_words, body, body_words * 8);
-        h_coeffs[staged] = coeffs[i] % c.t;
+        (void)centred(coeffs[i], &h_coeffs[staged]);
         any = true;
         if (++staged == group) flush();
     }

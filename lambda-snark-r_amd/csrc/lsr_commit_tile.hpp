@@ -4,7 +4,7 @@
 // pipeline (lsr_commit_fused.hpp), so lwe_commit (cpp-core/src/commitment.cpp:138-164, contract commitment.h:43-52) is one launch:
 //     for i < k : r_i <- chi (ChaCha20 stream + CDT search, in the lanes) -> 12 forward stages in LDS
 //                 acc[c] += A_hat[i][c] o r_hat_i (c < k),  acc[k] += b_hat[i] o r_hat_i
-//     for c <= k: 12 inverse stages (n^-1 folded into the last) -> + e1_c | + e2 + Delta (m mod t) -> the wire row, canonical
+//     for c <= k: 12 inverse stages (n^-1 folded into the last) -> + e1_c | + e2 + round(q (m mod t) / t) -> the wire row, canonical
 // instead of the eight launches of the unfused path (three samplers writing r, e1, e2 to memory, forward transforms, two matrix
 // products, inverse transforms, finish, pack): nothing but the finished row is written, nothing but the message is read.
 // lwe_verify_opening (commitment.cpp:200-232) is the same pipeline with the row's u as the source, s_hat as the one-column
@@ -44,21 +44,39 @@ __device__ __forceinline__ uint64_t decode_slot(uint64_t w, uint64_t t, const Mo
     return d == t ? 0 : d;
 }
 
-// m mod t for any 64-bit word and t < 2^21, in FP64 (a 64-bit integer division costs hundreds of instructions; the message embed
-// sits in the same lanes as the transforms).  Both steps reduce a value below 2^53 with one rounded quotient, an exact FMA remainder
-// and a fix-up of at most one t either way.
-struct PlainModulus {
-    double t, inv_t;
+// The message term of the scalar component: round(q (m mod t) / t) = floor((q m' + t/2) / t) for any 64-bit word m and t < 2^21,
+// in FP64 (a 64-bit integer division costs hundreds of instructions; the embed sits in the same lanes as the transforms).
+// Why not floor(q/t) m': with q = Delta t + rho a sum of commitments carries Delta M for the INTEGER M = sum c_i m_i, and
+// Delta M = Delta (M mod t) - rho floor(M/t) (mod q): the second term is noise of size rho sum c_i, five times the sampled noise at the
+// default modulus, which made combinations of large messages undecodable inside the noise budget.  With the rounded scaling the
+// sum is (q/t)(M mod t) + (at most sum c_i / 2) (mod q) (SEAL's BFV encryptor scales the same way for the same reason).
+// Every step reduces a value below 2^53 with one rounded quotient, an exact FMA remainder and a fix-up of at most one t either way.
+struct PlainScale {
+    double t, inv_t, delta, rho, half;          // t, 1/t, floor(q/t), q mod t, floor(t/2)
 };
-__device__ __forceinline__ double reduce_below_2p53(double x, const PlainModulus& m) {
-    const double k = __builtin_floor(x * m.inv_t);
-    double r = __builtin_fma(-k, m.t, x);                 // |x - k t| < 2 t: exact
-    r = r < 0.0 ? r + m.t : r;
-    return r >= m.t ? r - m.t : r;
+__host__ __device__ inline PlainScale make_plain_scale(uint64_t q, uint64_t t) {
+    return PlainScale{(double)t, 1.0 / (double)t, (double)(q / t), (double)(q % t), (double)(t >> 1)};
 }
-__device__ __forceinline__ double mod_plain(uint64_t word, const PlainModulus& m) {
-    const double hi = reduce_below_2p53((double)(uint32_t)(word >> 32), m);
-    return reduce_below_2p53(hi * 4294967296.0 + (double)(uint32_t)word, m);        // < 2^21 2^32 + 2^32 < 2^53
+// x = k t + r with 0 <= r < t for an integer 0 <= x < 2^53: returns r, *quot = k
+__device__ __forceinline__ double divmod_below_2p53(double x, const PlainScale& m, double* quot) {
+    double k = __builtin_floor(x * m.inv_t);
+    double r = __builtin_fma(-k, m.t, x);                 // |x - k t| < 2 t: exact
+    if (r < 0.0) { r += m.t; k -= 1.0; }
+    if (r >= m.t) { r -= m.t; k += 1.0; }
+    *quot = k;
+    return r;
+}
+__device__ __forceinline__ double mod_plain(uint64_t word, const PlainScale& m) {
+    double k;
+    const double hi = divmod_below_2p53((double)(uint32_t)(word >> 32), m, &k);
+    return divmod_below_2p53(hi * 4294967296.0 + (double)(uint32_t)word, m, &k);    // < 2^21 2^32 + 2^32 < 2^53
+}
+// round(q (word mod t) / t) = Delta m' + floor((rho m' + t/2) / t): both terms and their sum (< q < 2^45) are exact in FP64
+__device__ __forceinline__ double embed_plain(uint64_t word, const PlainScale& m) {
+    const double mm = mod_plain(word, m);
+    double k;
+    (void)divmod_below_2p53(m.rho * mm + m.half, m, &k);                             // rho m' + t/2 < 2^42
+    return m.delta * mm + k;
 }
 
 // One stream block (eight consecutive coefficients, block number = lane) of the Gaussian object (key, domain, index), left in `stage`
@@ -121,13 +139,12 @@ struct CommitTileSink {
         f8_sample_to_stage(key, c < K ? kDomE1 : kDomE2, c < K ? (uint32_t)c : 0u, tab, job.entries, stage);
         __syncthreads();
         uint64_t* const dst = row + kRowHeaderWords + ((size_t)c << 12);
-        const PlainModulus pm{(double)job.t, 1.0 / (double)job.t};
-        const double delta = (double)job.delta;
+        const PlainScale ps = make_plain_scale(job.q, job.t);
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) {
             const uint32_t idx = threadIdx.x + 512u * (uint32_t)k;
             double v = x[k] + (double)stage[idx];
-            if (c == K && idx < job.copy) v += delta * mod_plain(msg[idx], pm);     // Delta (t - 1) < q: exact
+            if (c == K && idx < job.copy) v += embed_plain(msg[idx], ps);           // < q: exact
             dst[idx] = u52_from_f64(canonical_f64(v, p.qd, p.inv_qd));              // |v| < 2 q + 2^15
         }
     }
@@ -346,14 +363,13 @@ __global__ void __launch_bounds__(256) commit_top_inverse_kernel(CommitTopJob jo
     top_round_sample<R>(tile, job.keys + 4 * (size_t)j, scalar ? kDomE2 : kDomE1, scalar ? 0u : c, lo, low0, tab, job.entries);
     __syncthreads();
     top_round_inverse<R>(v, tw, cs, p);
-    const PlainModulus pm{(double)job.t, 1.0 / (double)job.t};
-    const double delta = (double)job.delta;
+    const PlainScale ps = make_plain_scale(job.q, job.t);
     const uint64_t* const msg = job.msgs + (size_t)j * job.msg_len;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const uint32_t x = ((uint32_t)k << lo) + low0 + threadIdx.x;
         double out = v[k] + (double)tile[k * 256 + threadIdx.x];
-        if (scalar && x < job.copy) out += delta * mod_plain(msg[x], pm);
+        if (scalar && x < job.copy) out += embed_plain(msg[x], ps);
         __builtin_nontemporal_store(u52_from_f64(canonical_f64(out, p.qd, p.inv_qd)), data + ((size_t)k << lo));
     }
     if (c == 0 && low0 == 0 && threadIdx.x < kRowHeaderWords) {

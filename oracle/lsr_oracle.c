@@ -632,9 +632,16 @@ int oracle_lwe_commit(const oracle_lwe* c, const uint64_t* msg, size_t msg_len, 
     }
     inv_core(c->ntt, v);
     const size_t copy = msg_len < n ? msg_len : n;          /* commitment.cpp:146-149 truncation */
+    /* The message rides as round(q m / t) = floor((q m + t/2) / t), not as floor(q/t) m: with q = Delta t + rho a sum of commitments
+     * carries Delta M for the integer M = sum c_i m_i, and Delta M = Delta (M mod t) - rho floor(M / t) (mod q) — the second term is noise
+     * of size rho sum c_i (rho = 53217 for the default modulus: five times the sampled noise), which made combinations with
+     * sum c_i > ~130 of large messages undecodable although they passed the noise budget (round 3).  With the rounded scaling
+     * sum c_i round(q m_i / t) = (q/t) M + (rounding <= sum c_i / 2) = (q/t)(M mod t) (mod q): no rho term (what SEAL's BFV
+     * encryptor does for the same reason, multiply_add_plain_with_scaling_variant). */
     for (uint32_t x = 0; x < n; ++x) {
         uint64_t m = x < copy ? msg[x] % c->t : 0;
-        v[x] = (v[x] + e2[x] + oracle_mulmod(c->delta, m, q)) % q;
+        const uint64_t scaled = (uint64_t)((((u128)q * m) + (c->t >> 1)) / c->t);
+        v[x] = (v[x] + e2[x] + scaled) % q;
     }
     free(r); free(e1); free(e2);
     return 0;
@@ -684,15 +691,21 @@ int oracle_lwe_linear_combine(const oracle_lwe* c, const uint64_t* const* comms,
     const size_t body = (size_t)(c->k + 1) * c->n;
     int has = 0;
     double weight = 0;
+    /* coefficients act through their CENTRED representative mod t: c in (t/2, t) is the small negative number c - t, so a
+     * subtraction of commitments (coefficient t - 1) costs one unit of noise, not t - 1 */
     for (size_t i = 0; i < count; ++i)
-        if (comms[i]) weight += (double)(coeffs[i] % c->t);
-    if (weight * c->noise_unit >= 0.5 * (double)c->delta) return -1;  /* the result could not be opened (noise budget) */
+        if (comms[i]) {
+            const uint64_t cf = coeffs[i] % c->t;
+            weight += (double)(cf > c->t / 2 ? c->t - cf : cf);
+        }
+    if (weight * (c->noise_unit + 1.0) >= 0.5 * (double)c->delta) return -1;  /* the result could not be opened (noise budget) */
     memset(out, 0, sizeof(uint64_t) * (5 + body));
     for (size_t i = 0; i < count; ++i) {
         if (!comms[i]) continue;                                    /* commitment.cpp:248-250 */
         const uint64_t *u, *v;
         if (!parse(c, comms[i], lens[i], &u, &v)) return -1;
-        const uint64_t cf = coeffs[i] % c->t;                       /* commitment.cpp:90 */
+        uint64_t cf = coeffs[i] % c->t;                             /* commitment.cpp:90 */
+        if (cf > c->t / 2) cf = c->q - (c->t - cf);                 /* the centred representative, as a residue mod q */
         for (size_t x = 0; x < body; ++x) out[5 + x] = (out[5 + x] + oracle_mulmod(cf, u[x], c->q)) % c->q;
         has = 1;
     }

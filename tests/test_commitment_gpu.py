@@ -207,6 +207,32 @@ def test_linear_combine_bit_exact_vs_oracle(pkg, oracle):
     lctx.close()
 
 
+def test_combinations_of_large_messages_and_negative_coefficients(pkg, oracle):
+    """Round 3: (1) messages near t with sum c_i in the hundreds — the message rides as round(q m / t), so the integer overflow of
+    sum c_i m_i past t leaves no (q mod t)-sized noise (with floor(q/t) m such combinations passed the noise budget and failed to
+    open); (2) coefficients in (t/2, t) act as small negative numbers: a subtraction (t - 1) is inside the budget.  Words equal the
+    oracle's, the combination opens to sum c_i m_i mod t, and the budget still refuses what cannot open."""
+    q, n, k = 17592169062401, 4096, 2
+    lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=KEY)
+    t = lctx.plain_modulus
+    msgs = [[t - 1] * n, [t - 2] * n, list(range(t - n, t))]
+    coms = [pkg.Commitment(lctx, m, seed=500 + i) for i, m in enumerate(msgs)]
+    for j, m in enumerate(msgs):
+        assert np.array_equal(coms[j].as_words(), oracle.lwe_commit(q, n, k, 3.19, KEY, m, 500 + j))
+        assert pkg.verify_opening_with_context(lctx, coms[j], m)
+    for coeffs in ([100, 100, 0], [300, 200, 250], [t - 1, 1, 0], [t - 3, t - 400, 7], [1, t - 1, t - 1]):
+        comb = pkg.Commitment.linear_combine(lctx, coms, coeffs)
+        rc, want = oracle.lwe_linear_combine(q, n, k, 3.19, KEY, [c.as_words() for c in coms], coeffs)
+        assert rc == 0 and np.array_equal(comb.as_words(), want), coeffs
+        expect = [sum(c * m[i] for c, m in zip(coeffs, msgs)) % t for i in range(n)]
+        assert pkg.verify_opening_with_context(lctx, comb, expect), coeffs
+        assert oracle.lwe_verify(q, n, k, 3.19, KEY, comb.as_words(), expect) == 1
+    with pytest.raises(pkg.CoreError):
+        pkg.Commitment.linear_combine(lctx, coms, [500, 400, 0])          # sum |c_i| = 900 > ~800: refused, not returned
+    assert oracle.lwe_linear_combine(q, n, k, 3.19, KEY, [c.as_words() for c in coms], [500, 400, 0])[0] == -1
+    lctx.close()
+
+
 def test_commit_batch_matches_single_calls(pkg, oracle):
     q, n, k = 17592186044417, 4096, 2
     lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=KEY)

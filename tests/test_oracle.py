@@ -293,7 +293,9 @@ def test_noise_budget_is_enforced(oracle):
     cs = [oracle.lwe_commit(q, n, k, 3.19, 5, m, 10 + i) for i, m in enumerate([[1, 2], [3, 4]])]
     rc, out = oracle.lwe_linear_combine(q, n, k, 3.19, 5, cs, [700, 800])
     assert rc == 0 and oracle.lwe_verify(q, n, k, 3.19, 5, out, [(700 * 1 + 800 * 3) % t, (700 * 2 + 800 * 4) % t]) == 1
-    rc, _ = oracle.lwe_linear_combine(q, n, k, 3.19, 5, cs, [t - 1, 5])
+    rc, out = oracle.lwe_linear_combine(q, n, k, 3.19, 5, cs, [t - 1, 5])       # t - 1 acts as -1 (centred representative): inside the budget
+    assert rc == 0 and oracle.lwe_verify(q, n, k, 3.19, 5, out, [(-1 + 5 * 3) % t, (-2 + 5 * 4) % t]) == 1
+    rc, _ = oracle.lwe_linear_combine(q, n, k, 3.19, 5, cs, [t // 2, 5])
     assert rc == -1
     big = 1152921504606584833                                                # 60-bit prime = 1 (mod 2^18)
     cs = [oracle.lwe_commit(big, n, k, 3.19, 5, m, 10 + i) for i, m in enumerate([[1, 2], [3, 4]])]
@@ -327,3 +329,18 @@ def test_oracle_regression_vectors(oracle, golden_dir):
     for e in g["commit"]:
         c = oracle.lwe_commit(e["q"], e["n"], e["k"], e["sigma"], e["key_seed"], e["msg"], e["seed"])
         assert c.size == e["words"] and [int(x) for x in c[:8]] == e["head"] and sha(c) == e["sha256"]
+
+
+def test_commitment_combinations_survive_message_overflow_past_t(oracle):
+    """The oracle's own homomorphism at the edge the reference's pins do not reach (test_commitment.cpp:134-166 uses c in {2, 3} and
+    tiny messages): messages near t, sum c_i in the hundreds, negative coefficients as t - c."""
+    q, n, k, key = 17592169062401, 256, 2, 31
+    t = oracle.L.oracle_lwe_t(oracle.lwe_handle(q, n, k, 3.19, key))
+    m1, m2 = [t - 1] * n, [t - 2 - i for i in range(n)]
+    c1 = oracle.lwe_commit(q, n, k, 3.19, key, m1, 11)
+    c2 = oracle.lwe_commit(q, n, k, 3.19, key, m2, 12)
+    for cs in ([2, 3], [100, 100], [700, 300], [t - 1, 1], [t - 30, t - 40]):
+        rc, comb = oracle.lwe_linear_combine(q, n, k, 3.19, key, [c1, c2], cs)
+        assert rc == 0, cs
+        want = [(cs[0] * a + cs[1] * b) % t for a, b in zip(m1, m2)]
+        assert oracle.lwe_verify(q, n, k, 3.19, key, comb, want) == 1, cs
