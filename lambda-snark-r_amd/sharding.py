@@ -19,6 +19,26 @@ def shard_bounds(batch, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+_HOST_GROUP = None
+
+
+def host_group(group=None):
+    """The process group the host gathers run on.  They move CPU tensors, which an NCCL/RCCL group rejects: when the caller gives no
+    group and the default one is not gloo (bench.py initialises "nccl" for its barrier), a gloo group over all ranks is created once
+    and reused.  Collective: every rank must make its first call together.  An explicit non-gloo group is an error (round-2 advisor)."""
+    global _HOST_GROUP
+    import torch.distributed as dist
+    if group is not None:
+        if dist.get_backend(group) != "gloo":
+            raise ValueError("gather_batches moves host tensors: pass a gloo group (got backend %r)" % dist.get_backend(group))
+        return group
+    if dist.get_backend() == "gloo":
+        return None
+    if _HOST_GROUP is None:
+        _HOST_GROUP = dist.new_group(backend="gloo")
+    return _HOST_GROUP
+
+
 def gather_batches(local, dst=0, group=None):
     """Gather per-rank [local_batch, ...] host arrays into ONE preallocated array on `dst` (None elsewhere), in rank order.
     The rows travel as raw tensor bytes (``dist.gather`` of int64 views, no pickling); the slice sizes follow from
@@ -28,6 +48,7 @@ def gather_batches(local, dst=0, group=None):
     local = np.ascontiguousarray(local)
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
+    group = host_group(group)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64), group=group)

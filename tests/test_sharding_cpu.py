@@ -40,6 +40,7 @@ def _worker(rank, world, port, batch, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     q, n = 12289, 256
     polys = orc.splitmix(0xABC, q, batch * n).reshape(batch, n)          # same synthetic batch on every rank
+    assert sh.host_group() is None                      # the default group is gloo: the gathers run on it (an NCCL default gets a gloo twin)
     got = sh.sharded_transform(polys, lambda a: orc.ntt_forward(q, n, a))
     if rank == 0:
         np.save(out_path, got)
