@@ -30,6 +30,12 @@
 #include "lsr_runtime.hpp"
 #include "lsr_sampler.hpp"
 
+// full commitments at n >= 2^16, rank 4: 1 = one pass of the middle stage with five accumulators (a few spilled registers),
+// 0 = the A^T product and the b_hat product as two passes over the workspace (build-time A/B switch, csrc/Makefile EXTRA=)
+#ifndef LSR_K4_SINGLE_PASS
+#define LSR_K4_SINGLE_PASS 1
+#endif
+
 namespace lsr {
 
 constexpr uint64_t kWireMagic = kRowMagic;                // "LSRC0001" (lsr_commit_tile.hpp)
@@ -435,7 +441,7 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
         };
         if (fused_eligible(*c)) permute(c->a_perm, nullptr, 0u, k);
         if (tile_eligible(*c) || (fused_eligible(*c) && c->cdf_entries <= 64)) {
-            if (c->logn == 12 || k <= 3) permute(c->ab_perm, c->b_hat.ptr, 0u, k + 1);
+            if (c->logn == 12 || k <= 3 || LSR_K4_SINGLE_PASS) permute(c->ab_perm, c->b_hat.ptr, 0u, k + 1);
             else permute(c->b_perm, c->b_hat.ptr, k, 1u);
             permute(c->s_perm, c->s_hat.ptr, k, 1u);
         }
@@ -504,6 +510,10 @@ constexpr int kMixedLanes = 2;                            // independent pipelin
 constexpr uint32_t kMixedForwardGroups = 2;               // 256-lane groups per half workgroup in the forward role
 constexpr size_t kFusedChunkBytes = size_t(128) << 20;    // three-launch schedule, blinding residues given
 constexpr size_t kSampledChunkBytes = size_t(64) << 20;   // three-launch schedule, blinding residues sampled in the strided rounds
+#ifndef LSR_FULL_CHUNK_MIB
+#define LSR_FULL_CHUNK_MIB 64
+#endif
+constexpr size_t kFullCommitChunkBytes = size_t(LSR_FULL_CHUNK_MIB) << 20;   // full commitments at n >= 2^16: witness workspace per chunk
 constexpr int kFusedStreams = 2;                          // chunk lanes of the three-launch schedule (lane 0 = the caller's stream)
 
 template <int K>
@@ -846,7 +856,7 @@ static void commit_rows_fused(const LweContext& c, const uint64_t* d_msgs, size_
                               hipStream_t s) {
     const uint32_t k = c.k, n = c.n;
     const size_t vec_words = (size_t)k << c.logn, row_words = kHeaderWords + ((size_t)k + 1) * n;
-    const size_t chunk = std::max<size_t>(1, kSampledChunkBytes / (vec_words * 8));
+    const size_t chunk = std::max<size_t>(1, kFullCommitChunkBytes / (vec_words * 8));
     const int streams = static_cast<int>(std::min<size_t>((size_t)kFusedStreams, (batch + chunk - 1) / chunk));
     ensure_side_streams(c, streams);
     const size_t slot_words = std::min(chunk, batch) * vec_words;
@@ -870,9 +880,13 @@ static void commit_rows_fused(const LweContext& c, const uint64_t* d_msgs, size_
             case 1: launch_mid_general<1, 2>(c, ws, vec_words, body, row_words, c.ab_perm.ptr, now, st); break;
             case 2: launch_mid_general<2, 3>(c, ws, vec_words, body, row_words, c.ab_perm.ptr, now, st); break;
             case 3: launch_mid_general<3, 4>(c, ws, vec_words, body, row_words, c.ab_perm.ptr, now, st); break;
-            default:   // five accumulators do not fit the stage's 128 VGPRs: A^T first, then b_hat as a one-column pass over the same workspace
+            default:
+#if LSR_K4_SINGLE_PASS     // five accumulators: 128 VGPRs with a few spilled registers, against a second one-column pass over the workspace
+                launch_mid_general<4, 5>(c, ws, vec_words, body, row_words, c.ab_perm.ptr, now, st);
+#else
                 launch_mid_general<4, 4>(c, ws, vec_words, body, row_words, c.a_perm.ptr, now, st);
                 launch_mid_general<4, 1>(c, ws, vec_words, body + vec_words, row_words, c.b_perm.ptr, now, st);
+#endif
         }
         if (r == 4) hipLaunchKernelGGL((commit_top_inverse_kernel<4>), dim3(grid_i), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->inv_f64.ptr, cs);
         else hipLaunchKernelGGL((commit_top_inverse_kernel<5>), dim3(grid_i), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->inv_f64.ptr, cs);

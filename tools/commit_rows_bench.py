@@ -13,6 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
 
 pkg = entry.load_package()
+if os.environ.get("LIBVARIANT"):          # an experiment build of the library (csrc/Makefile VARIANT=...), loaded explicitly
+    pkg._abi.use_library(os.path.join(os.path.dirname(pkg._abi.LIB_PATH), "liblambda_snark_core_%s.so" % os.environ["LIBVARIANT"]))
 lib = pkg._abi.lib()
 N, K = int(os.environ.get("N", 4096)), int(os.environ.get("K", 2))
 J, MSG, REPS = int(os.environ.get("J", 16384)), int(os.environ.get("MSG", 16)), int(os.environ.get("REPS", 10))
