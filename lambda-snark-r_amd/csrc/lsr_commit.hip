@@ -265,7 +265,7 @@ struct LweContext {
     lsr::DeviceBuffer<double> s_perm;       // [tile][k][1]: s_hat, the one-column matrix of an opening
     mutable lsr::DeviceBuffer<uint64_t> ws_rows;                    // wire rows of a chunk on their way to host allocations
     mutable lsr::DeviceBuffer<unsigned long long> ws_vflags;        // openings: per-row OR of decoded ^ claimed
-    mutable lsr::DeviceBuffer<uint32_t> ws_vbad;                    // openings: per-row "not a canonical commitment of this context"
+    mutable uint32_t* ws_vbad = nullptr;                            // openings: per-row "not a canonical commitment of this context" (inside ws_vflags)
     mutable lsr::DeviceBuffer<uint64_t> ws_mid, ws_e1_slots;
     mutable hipStream_t side[kMaxSide] = {nullptr, nullptr};
     mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr};
@@ -472,7 +472,7 @@ static void destroy_lwe_context(LweContext* c) {
         c->ws_r.release(); c->ws_e1.release(); c->ws_e2.release(); c->ws_u.release(); c->ws_v.release();
         c->ws_dm.release(); c->ws_keys.release(); c->ws_flag.release();
         c->a_perm.release(); c->ab_perm.release(); c->b_perm.release(); c->ws_mid.release(); c->ws_rows.release();
-        c->ws_vflags.release(); c->ws_vbad.release();
+        c->ws_vflags.release();
         if (c->s_perm.ptr) (void)hipMemset(c->s_perm.ptr, 0, c->s_perm.count * 8);
         c->s_perm.release();
         if (c->ws_e1_slots.ptr) (void)hipMemset(c->ws_e1_slots.ptr, 0, c->ws_e1_slots.count * 8);
@@ -1033,11 +1033,13 @@ static void launch_verify_tile(const LweContext& c, const VerifyTileJob& job, hi
 static void verify_rows_device(const LweContext& c, const uint64_t* d_rows, const uint64_t* d_msgs, size_t msg_len, size_t count, hipStream_t s) {
     const uint32_t n = c.n, k = c.k;
     const size_t kn = (size_t)k * n, row = kHeaderWords + kn + n;
-    if (c.ws_vflags.count < count) { c.ws_vflags.allocate(count); c.ws_vbad.allocate(count); }
-    LSR_HIP(hipMemsetAsync(c.ws_vflags.ptr, 0, count * sizeof(unsigned long long), s));
-    LSR_HIP(hipMemsetAsync(c.ws_vbad.ptr, 0, count * sizeof(uint32_t), s));
+    // one allocation, one clear, one copy back: [flags: count x u64 | bad: count x u32]
+    const size_t state_words = count + (count + 1) / 2;
+    if (c.ws_vflags.count < state_words) c.ws_vflags.allocate(state_words);
+    c.ws_vbad = reinterpret_cast<uint32_t*>(c.ws_vflags.ptr + count);
+    LSR_HIP(hipMemsetAsync(c.ws_vflags.ptr, 0, state_words * sizeof(unsigned long long), s));
     if (c.s_perm.ptr && c.logn == 12) {     // one launch, one workgroup per opening: the row is read once (lsr_commit_tile.hpp)
-        const VerifyTileJob job{d_rows, d_msgs, (uint64_t)msg_len, c.ws_vflags.ptr, c.ws_vbad.ptr, (uint32_t)count, c.q, c.t};
+        const VerifyTileJob job{d_rows, d_msgs, (uint64_t)msg_len, c.ws_vflags.ptr, c.ws_vbad, (uint32_t)count, c.q, c.t};
         switch (k) {
             case 1: launch_verify_tile<1>(c, job, s); break;
             case 2: launch_verify_tile<2>(c, job, s); break;
@@ -1058,7 +1060,7 @@ static void verify_rows_device(const LweContext& c, const uint64_t* d_rows, cons
             uint64_t* const ws = c.ws_mid.ptr;
             uint64_t* const ws_out = c.ws_mid.ptr + slot * vec_words;
             const VerifyTopJob job{d_rows + first * row, ws, ws_out, d_msgs + first * msg_len, (uint64_t)msg_len, (uint64_t)row, c.ws_vflags.ptr + first,
-                                   c.ws_vbad.ptr + first, (uint32_t)now, k, c.q, c.t};
+                                   c.ws_vbad + first, (uint32_t)now, k, c.q, c.t};
             const unsigned grid_f = static_cast<unsigned>((now * k << c.logn) >> (r + 8)), grid_i = static_cast<unsigned>((now << c.logn) >> (r + 8));
             if (r == 4) hipLaunchKernelGGL((verify_top_forward_kernel<4>), dim3(grid_f), dim3(256), 0, s, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
             else hipLaunchKernelGGL((verify_top_forward_kernel<5>), dim3(grid_f), dim3(256), 0, s, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
@@ -1076,7 +1078,7 @@ static void verify_rows_device(const LweContext& c, const uint64_t* d_rows, cons
     }
     // general form: split the rows (header and canonicity checks on the way), transform, product, subtract, inverse, decode
     ensure_workspace(c, count);
-    hipLaunchKernelGGL(unpack_commitments_kernel, dim3(grid_for(count * row)), dim3(256), 0, s, d_rows, c.ws_u.ptr, c.ws_v.ptr, c.ws_vbad.ptr, (uint64_t)kn,
+    hipLaunchKernelGGL(unpack_commitments_kernel, dim3(grid_for(count * row)), dim3(256), 0, s, d_rows, c.ws_u.ptr, c.ws_v.ptr, c.ws_vbad, (uint64_t)kn,
                        (uint64_t)n, (uint64_t)count, c.q, c.t, (uint64_t)n | ((uint64_t)k << 32));
     launch_ntt(*c.ntt, c.ws_u.ptr, count * k, false, s);
     launch_ntt(*c.ntt, c.ws_v.ptr, count, false, s);
@@ -1101,17 +1103,16 @@ static void verify_host_rows(const LweContext& c, const uint64_t* rows, const ui
     const size_t chunk = verify_chunk(c, count);
     if (c.ws_rows.count < chunk * row) c.ws_rows.allocate(chunk * row);
     DeviceBuffer<uint64_t> d_msgs(chunk * msg_len);
-    std::vector<unsigned long long> host_flags(chunk);
-    std::vector<uint32_t> host_bad(chunk);
+    std::vector<unsigned long long> state(chunk + (chunk + 1) / 2);
     for (size_t first = 0; first < count; first += chunk) {
         const size_t now = std::min(chunk, count - first);
         LSR_HIP(hipMemcpyAsync(c.ws_rows.ptr, rows + first * row, now * row * 8, hipMemcpyHostToDevice, s));
         LSR_HIP(hipMemcpyAsync(d_msgs.ptr, messages + first * msg_len, now * msg_len * 8, hipMemcpyHostToDevice, s));
         verify_rows_device(c, c.ws_rows.ptr, d_msgs.ptr, msg_len, now, s);
-        LSR_HIP(hipMemcpyAsync(host_flags.data(), c.ws_vflags.ptr, now * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        LSR_HIP(hipMemcpyAsync(host_bad.data(), c.ws_vbad.ptr, now * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipMemcpyAsync(state.data(), c.ws_vflags.ptr, (now + (now + 1) / 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         LSR_HIP(hipStreamSynchronize(s));
-        for (size_t j = 0; j < now; ++j) results[first + j] = host_bad[j] ? -1 : (host_flags[j] == 0 ? 1 : 0);
+        const uint32_t* const host_bad = reinterpret_cast<const uint32_t*>(state.data() + now);
+        for (size_t j = 0; j < now; ++j) results[first + j] = host_bad[j] ? -1 : (state[j] == 0 ? 1 : 0);
     }
 }
 
@@ -1484,7 +1485,7 @@ int lsr_lwe_verify_rows_device(const LweContext* ctx, const uint64_t* d_rows, co
         hipStream_t s = static_cast<hipStream_t>(stream);
         lsr::begin_async(*ctx, s);
         lsr::verify_rows_device(*ctx, d_rows, d_messages, msg_len, count, s);
-        hipLaunchKernelGGL(lsr::opening_verdict_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, ctx->ws_vflags.ptr, ctx->ws_vbad.ptr, d_results,
+        hipLaunchKernelGGL(lsr::opening_verdict_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, ctx->ws_vflags.ptr, ctx->ws_vbad, d_results,
                            (uint64_t)count);
         LSR_HIP(hipGetLastError());
         lsr::end_async(*ctx, s);

@@ -180,19 +180,17 @@ struct LsrQuotientPlan {
     lsr::DeviceBuffer<uint32_t> io_len;
     size_t chunk = 0;
     hipStream_t stream = nullptr;
+    // read from the environment ONCE, when the plan is created
+    int chunk_log2 = 26;                      // LAMBDA_SNARK_QUOTIENT_CHUNK_LOG2: evaluations per pass and plane
+    bool fuse = true;                         // LAMBDA_SNARK_QUOTIENT_FUSE=0: the a b = c test and the coset product as kernels of their own
 };
 
 namespace lsr {
 
-// instances per pass: bound the workspace (3 m words per instance; 2^26 evaluations per vector ~ 1.5 GiB).
-// LAMBDA_SNARK_QUOTIENT_CHUNK_LOG2 overrides the exponent (tests use it to force several passes).
+// instances per pass: bound the workspace (3 m words per instance; 2^26 evaluations per vector ~ 1.5 GiB; p.chunk_log2: tests force
+// several passes with LAMBDA_SNARK_QUOTIENT_CHUNK_LOG2 at plan creation)
 static size_t quotient_chunk(const LsrQuotientPlan& p, size_t batch) {
-    int log2_words = 26;
-    if (const char* e = std::getenv("LAMBDA_SNARK_QUOTIENT_CHUNK_LOG2")) {
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 30) log2_words = v;
-    }
-    const size_t cap = std::max<size_t>(1, (size_t(1) << log2_words) >> p.logm);
+    const size_t cap = std::max<size_t>(1, (size_t(1) << p.chunk_log2) >> p.logm);
     return std::min(batch, cap);
 }
 
@@ -220,9 +218,8 @@ static void quotient_pass(LsrQuotientPlan& p, const uint64_t* d_a, const uint64_
     LSR_HIP(hipMemsetAsync(p.flags.ptr, 0, 2 * count * sizeof(uint32_t), s));
     // m <= 4096 (one tile launch per transform): the two elementwise kernels ride in the read-in of a transform — the a b = c test in
     // C's interpolation, the coset product in the last transform (the transforms are integer-VALU-bound, the extra loads cost nothing
-    // and two passes over the planes disappear: profiles/r02b_quotient_fusion.txt).  LAMBDA_SNARK_QUOTIENT_FUSE=0 keeps them apart.
-    const char* const fuse_env = std::getenv("LAMBDA_SNARK_QUOTIENT_FUSE");
-    const bool fuse = !(fuse_env && fuse_env[0] == '0') && p.ntt && ntt_forward_can_fuse(*p.ntt);
+    // and two passes over the planes disappear: profiles/r02b_quotient_fusion.txt).  A plan created under LAMBDA_SNARK_QUOTIENT_FUSE=0 keeps them apart.
+    const bool fuse = p.fuse && p.ntt && ntt_forward_can_fuse(*p.ntt);
     const bool fuse_check = fuse && d_a != work;
     if (!fuse_check) hipLaunchKernelGGL(check_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, d_a, d_b, d_c, bad, p.logm, per_vector);
     if (p.ntt) {
@@ -324,6 +321,11 @@ static LsrQuotientPlan* create_plan(uint32_t m, int device) {
     auto* p = new LsrQuotientPlan;
     p->m = m;
     p->device = device;
+    if (const char* e = std::getenv("LAMBDA_SNARK_QUOTIENT_CHUNK_LOG2")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 30) p->chunk_log2 = v;
+    }
+    if (const char* e = std::getenv("LAMBDA_SNARK_QUOTIENT_FUSE")) p->fuse = !(e[0] == '0');
     while ((1u << p->logm) < m) ++p->logm;
     const uint64_t q = kProverModulus;
     if (m >= 2) {

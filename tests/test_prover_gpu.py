@@ -252,17 +252,19 @@ def test_quotient_fused_elementwise_stages_agree(pkg, oracle, m, monkeypatch):
     for v in (a, b, c):                           # non-canonical representatives of small residues
         small = v < np.uint64(2**32 - 1)
         v[small] = v[small] + np.uint64(Q)
-    plan = pkg.QuotientPlan(m, device=0)
     da, db, dc = (torch.from_numpy(v.view(np.int64)).cuda() for v in (a, b, c))
     s = torch.cuda.current_stream().cuda_stream
     out = {}
     for fuse in ("1", "0"):
-        monkeypatch.setenv("LAMBDA_SNARK_QUOTIENT_FUSE", fuse)
+        monkeypatch.setenv("LAMBDA_SNARK_QUOTIENT_FUSE", fuse)     # read once, when the plan is created
+        plan = pkg.QuotientPlan(m, device=0)
+        monkeypatch.setenv("LAMBDA_SNARK_QUOTIENT_FUSE", "1" if fuse == "0" else "0")
         dq = torch.zeros_like(da)
         dl = torch.full((batch,), -1, dtype=torch.int32, device="cuda")
         plan.quotient_device(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, dq.data_ptr(), dl.data_ptr(), s)
         torch.cuda.synchronize()
         out[fuse] = (dq.cpu().numpy().view(np.uint64), dl.cpu().numpy().view(np.uint32))
+        plan.close()
     assert np.array_equal(out["1"][1], out["0"][1])
     lens = out["1"][1]
     assert all(lens[i] == 0 for i in spoil) and (np.delete(lens, list(spoil)) >= 1).all()
@@ -271,7 +273,6 @@ def test_quotient_fused_elementwise_stages_agree(pkg, oracle, m, monkeypatch):
     for i in (1, batch // 2, batch - 2):
         want, ln = oracle.quotient(a[i] % np.uint64(Q), b[i] % np.uint64(Q), c[i] % np.uint64(Q))
         assert lens[i] == ln and np.array_equal(out["1"][0][i], want)
-    plan.close()
 
 
 # ---- compute_quotient_poly(witness) in full: sparse products + pipeline -------------------------------------------------

@@ -41,7 +41,7 @@ def report(what, **kw):
 
 while time.time() < deadline:
     cases += 1
-    which = rng.integers(0, 12)
+    which = rng.integers(0, 14)
     if which < 5:            # negacyclic transforms, both flavours
         logn = int(rng.integers(1, 18)); n = 1 << logn
         bits = int(rng.integers(max(logn + 3, 14), 61))
@@ -165,11 +165,47 @@ while time.time() < deadline:
         want = np.ones(cnt, dtype=np.int32); want[victim] = 0
         if not np.array_equal(out, want): report("flat verify", n=n, k=k, got=out.tolist(), victim=victim)
         coeffs = [int(x) for x in rng.integers(0, 8, size=cnt)]
+        if rng.integers(0, 2): coeffs[0] = int(ctx.plain_modulus) - int(rng.integers(1, 40))     # a small negative number (centred representative)
+        if rng.integers(0, 3) == 0: coeffs[-1] = int(rng.integers(8, 60))
         comb = pkg.Commitment.linear_combine(ctx, coms, coeffs)
         rc, want = orc.lwe_linear_combine(q, n, k, 3.19, seed_key, [cm.as_words() for cm in coms], coeffs)
         if rc != 0 or not np.array_equal(comb.as_words(), want): report("linear combine", n=n, k=k, cnt=cnt)
         for cm in coms + [comb]: cm.free()
         ctx.close()
+    elif which in (12, 13):  # whole commitments / openings, device-resident rows: tile pipeline (n = 4096), fused (2^16, 2^17), general (others)
+        import torch
+        logn = int([12, 12, 12, 16, 16, 17, 10, 13][int(rng.integers(0, 8))]); n = 1 << logn
+        k = int(rng.integers(1, 5))
+        q = prime_for(n, 44)
+        batch = int(rng.integers(1, 70)) if logn <= 13 else int(rng.integers(1, 6)) if rng.integers(0, 3) else int(rng.integers(30, 40))
+        seed_key = int(rng.integers(1, 2**62))
+        ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=seed_key)
+        t = ctx.plain_modulus
+        ml = int([1, 5, n, n + 2, int(rng.integers(1, n + 1))][int(rng.integers(0, 5))])
+        msgs = rng.integers(0, t, size=(batch, ml), dtype=np.uint64)
+        seeds = rng.integers(1, 2**62, size=batch, dtype=np.uint64)
+        keys = np.zeros((batch, 4), dtype=np.uint64)
+        if lib.lsr_lwe_commit_keys(ctx.handle, msgs.ctypes.data, ml, batch, seeds.ctypes.data, keys.ctypes.data) != 0: report("commit keys rc")
+        words = lib.lsr_lwe_commitment_words(ctx.handle)
+        st = torch.cuda.current_stream().cuda_stream
+        d_msgs = torch.from_numpy(msgs.view(np.int64)).cuda(); d_keys = torch.from_numpy(keys.view(np.int64)).cuda()
+        d_rows = torch.zeros((batch, words), dtype=torch.int64, device="cuda")
+        if lib.lsr_lwe_commit_rows_device(ctx.handle, d_msgs.data_ptr(), ml, batch, d_keys.data_ptr(), d_rows.data_ptr(), st) != 0: report("commit rows rc")
+        torch.cuda.synchronize()
+        picks = sorted({0, batch - 1, int(rng.integers(0, batch))})
+        host = d_rows[picks].cpu().numpy().view(np.uint64)
+        for i, j in enumerate(picks):
+            if not np.array_equal(host[i], orc.lwe_commit(q, n, k, 3.19, seed_key, msgs[j], int(seeds[j]))):
+                report("commit rows", n=n, k=k, batch=batch, ml=ml, j=j, pipeline=lib.lsr_lwe_pipeline(ctx.handle).decode())
+        vl = min(ml, n)
+        claims = np.ascontiguousarray(msgs[:, :vl]).copy(); victim = int(rng.integers(0, batch)); claims[victim, int(rng.integers(0, vl))] ^= np.uint64(1)
+        d_claims = torch.from_numpy(claims.view(np.int64)).cuda()
+        res = torch.full((batch,), 9, dtype=torch.int32, device="cuda")
+        if lib.lsr_lwe_verify_rows_device(ctx.handle, d_rows.data_ptr(), d_claims.data_ptr(), vl, batch, res.data_ptr(), st) != 0: report("verify rows rc")
+        torch.cuda.synchronize()
+        want = np.ones(batch, dtype=np.int32); want[victim] = 0
+        if not np.array_equal(res.cpu().numpy(), want): report("verify rows", n=n, k=k, batch=batch, vl=vl, victim=victim)
+        ctx.close(); del d_rows, d_msgs, d_keys
     else:                    # commitments
         n = 1 << int(rng.integers(1, 13)); k = int(rng.integers(1, 5))
         q = [12289, 17592186044417, 17592169062401, prime_for(n, int(rng.integers(41, 61)))][int(rng.integers(0, 4))]

@@ -27,3 +27,13 @@ def cp(dst):
 print("torch D2H to torch-pinned", [round(cp(tp), 2) for _ in range(3)])
 pa = torch.from_numpy(pin.array.view(np.int64))
 print("torch D2H to lsr-pinned (as pageable view)", [round(cp(pa), 2) for _ in range(3)])
+# bench.py's order: commit pageable, verify pageable, allocate pinned, commit pinned, verify pinned — three times
+ver = np.zeros(nb, dtype=np.int32)
+for rnd in range(3):
+    a = wall(lambda: lib.lsr_lwe_commit_batch_flat(ctx.handle, msgs.ctypes.data, 8, nb, seeds.ctypes.data, rows.ctypes.data), reps=3)
+    b = wall(lambda: lib.lsr_lwe_verify_opening_batch_flat(ctx.handle, rows.ctypes.data, msgs.ctypes.data, 8, nb, ver.ctypes.data), reps=3)
+    p2 = pkg.PinnedArray(rows.shape)
+    c = wall(lambda: lib.lsr_lwe_commit_batch_flat(ctx.handle, msgs.ctypes.data, 8, nb, seeds.ctypes.data, p2.ptr), reps=3)
+    d2 = wall(lambda: lib.lsr_lwe_verify_opening_batch_flat(ctx.handle, p2.ptr, msgs.ctypes.data, 8, nb, ver.ctypes.data), reps=3)
+    print("round", rnd, "commit pageable", a, "verify", b, "commit pinned", c, "verify pinned", d2)
+    p2.close()
