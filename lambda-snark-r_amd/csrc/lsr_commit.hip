@@ -257,7 +257,7 @@ struct LweContext {
     mutable uint64_t* host_stage = nullptr;
     mutable size_t host_stage_words = 0;
     // fused matrix–vector pipeline (lsr_commit_fused.hpp): lane-major copy of A_hat, per-lane chunk workspaces, side streams
-    static constexpr int kMaxSide = 2;
+    static constexpr int kMaxSide = 3;
     lsr::DeviceBuffer<double> a_perm;       // [tile][k][k]: the A^T product (n = 2^16 / 2^17)
     // full commitments and openings on the tile pipeline (lsr_commit_tile.hpp; n = 4096, 2^16, 2^17):
     lsr::DeviceBuffer<double> ab_perm;      // [tile][k][k + 1]: A^T and b_hat in one pass (n = 4096: k <= 4; larger n: k <= 3)
@@ -267,8 +267,8 @@ struct LweContext {
     mutable lsr::DeviceBuffer<unsigned long long> ws_vflags;        // openings: per-row OR of decoded ^ claimed
     mutable uint32_t* ws_vbad = nullptr;                            // openings: per-row "not a canonical commitment of this context" (inside ws_vflags)
     mutable lsr::DeviceBuffer<uint64_t> ws_mid, ws_e1_slots;
-    mutable hipStream_t side[kMaxSide] = {nullptr, nullptr};
-    mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr};
+    mutable hipStream_t side[kMaxSide] = {nullptr, nullptr, nullptr};
+    mutable hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {nullptr, nullptr, nullptr};
     mutable int n_side = 0;
     // asynchronous entry points share the context's workspaces and side streams: each call's stream first waits for the previous
     // call's last kernel (recorded here), so calls on one context are ordered whatever streams the caller brings
@@ -509,12 +509,18 @@ constexpr size_t kMixedChunkBytes = size_t(64) << 20;     // mixed launches: 2 l
 constexpr int kMixedLanes = 2;                            // independent pipelines of mixed launches (lane 0 = the caller's stream)
 constexpr uint32_t kMixedForwardGroups = 2;               // 256-lane groups per half workgroup in the forward role
 constexpr size_t kFusedChunkBytes = size_t(128) << 20;    // three-launch schedule, blinding residues given
-constexpr size_t kSampledChunkBytes = size_t(64) << 20;   // three-launch schedule, blinding residues sampled in the strided rounds
+#ifndef LSR_SAMPLED_CHUNK_MIB
+#define LSR_SAMPLED_CHUNK_MIB 64
+#endif
+#ifndef LSR_FUSED_STREAMS
+#define LSR_FUSED_STREAMS 2
+#endif
+constexpr size_t kSampledChunkBytes = size_t(LSR_SAMPLED_CHUNK_MIB) << 20;   // three-launch schedule, blinding residues sampled in the strided rounds
 #ifndef LSR_FULL_CHUNK_MIB
 #define LSR_FULL_CHUNK_MIB 64
 #endif
 constexpr size_t kFullCommitChunkBytes = size_t(LSR_FULL_CHUNK_MIB) << 20;   // full commitments at n >= 2^16: witness workspace per chunk
-constexpr int kFusedStreams = 2;                          // chunk lanes of the three-launch schedule (lane 0 = the caller's stream)
+constexpr int kFusedStreams = LSR_FUSED_STREAMS;                          // chunk lanes of the three-launch schedule (lane 0 = the caller's stream)
 
 template <int K>
 static void launch_mid(const LweContext& c, const uint64_t* ws, uint64_t* d_u, size_t vectors, hipStream_t s) {

@@ -234,3 +234,22 @@ def test_host_pointer_commit_and_verify_at_config3_shape(pkg, oracle, lib):
     want = [2 * a + 3 * 7 for a in m1] + [21] * (n - len(m1))
     assert pkg.verify_opening_with_context(ctx, comb, want)
     ctx.close()
+
+
+@pytest.mark.parametrize("sigma,n,k,want", [(5.0, 4096, 2, "tile"), (6.5, 4096, 1, "tile"), (3.45, 4096, 3, "tile"), (5.0, 65536, 2, "fused"), (7.5, 4096, 2, "general")])
+def test_table_sizes_around_the_lane_table_limits(pkg, oracle, sigma, n, k, want):
+    """The in-lane table search has a 5-step form (<= 32 scanned entries, sigma <= ~3.4), a 6-step form (<= 64, sigma <= ~6.9) and gives
+    way to the linear LDS scan (and the general commitment kernels) beyond: whole commitments equal the oracle's on each side of both
+    limits, and open."""
+    q = oracle.L.oracle_lwe_select_modulus(0, n)
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=sigma), key_seed=KEY)
+    assert _pipeline(ctx) == want
+    rng = np.random.default_rng(int(sigma * 100) + n)
+    batch, msg_len = 3, 9
+    msgs = rng.integers(0, ctx.plain_modulus, size=(batch, msg_len), dtype=np.uint64)
+    seeds = rng.integers(1, 2**63, size=batch, dtype=np.uint64)
+    rows = _rows_device(ctx, msgs, _keys(ctx, msgs, seeds)).cpu().numpy().view(np.uint64)
+    for j in range(batch):
+        assert np.array_equal(rows[j], oracle.lwe_commit(q, n, k, sigma, KEY, [int(x) for x in msgs[j]], int(seeds[j]))), (sigma, n, k, j)
+    assert pkg.verify_openings_words(ctx, rows, msgs) == [1] * batch
+    ctx.close()

@@ -159,7 +159,7 @@ def test_sample_gaussian_moments(pkg):
     assert not np.array_equal(pkg.sample_gaussian(64, 3.2), pkg.sample_gaussian(64, 3.2))   # fresh entropy per call
 
 
-@pytest.mark.parametrize("sigma,length", [(3.19, 4096), (3.2, 1001), (0.4, 77), (20.0, 4099), (100.0, 513)])
+@pytest.mark.parametrize("sigma,length", [(3.19, 4096), (3.2, 1001), (0.4, 77), (20.0, 4099), (100.0, 513), (3.45, 4096), (5.0, 4100), (6.9, 999), (7.1, 640)])
 def test_seeded_sampler_bit_exact(pkg, oracle, sigma, length):
     got = pkg.sample_gaussian(length, sigma, seed=0xFEED, domain=5, index=3)
     assert np.array_equal(got, oracle.sample_gaussian_seeded(length, sigma, 0xFEED, 5, 3))

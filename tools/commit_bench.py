@@ -2,7 +2,10 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
-pkg = entry.load_package(); lib = pkg._abi.lib()
+pkg = entry.load_package()
+if os.environ.get("LIBVARIANT"):          # an experiment build of the library (csrc/Makefile VARIANT=...), loaded explicitly
+    pkg._abi.use_library(os.path.join(os.path.dirname(pkg._abi.LIB_PATH), "liblambda_snark_core_%s.so" % os.environ["LIBVARIANT"]))
+lib = pkg._abi.lib()
 Q, N, K = 17592182243329, 65536, int(os.environ.get("K", 4))
 J = int(os.environ.get("J", 1024))
 lctx = pkg.LweContext(pkg.Params(q=Q, n=N, k=K, sigma=3.19), key_seed=7, device=0)
