@@ -199,7 +199,15 @@ struct VerifyTileSource {
         }
         if (!ok) atomicOr(bad, 1u);
     }
-    __device__ __forceinline__ uint32_t ahead(int) const { return 0; }
+    // pull the next polynomial of the row (after the last u_i: v, which the sink reads) towards this XCD's L2 while the current one
+    // is being transformed: one dword per 128-byte line, as the middle stage of the large degrees does
+    __device__ __forceinline__ uint32_t ahead(int i) const {
+        if (threadIdx.x < 256) {
+            const rsrc_t nxt = make_rsrc(row + kRowHeaderWords + ((size_t)(i + 1) << 12), 4096u * 8u);
+            return __builtin_amdgcn_raw_buffer_load_b32(nxt, (int)(threadIdx.x * 128u), 0, 0);
+        }
+        return 0;
+    }
 };
 // w = v - INTT(<s_hat, u_hat>), decoded slot by slot and compared with the claimed words as given
 template <int K>

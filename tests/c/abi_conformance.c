@@ -132,6 +132,30 @@ static void test_commitment(void) {
         CHECK(lwe_verify_opening(ctx, combined, expected, 4, &opening) == 0);
         lwe_commitment_free(c1); lwe_commitment_free(c2); lwe_commitment_free(combined);
     }
+    {   /* the batched twins a C caller would use (batch.h): the same commitment as a row of one array, opened in one pass; the
+           reference's parameters take the one-workgroup-per-commitment path */
+        enum { B = 3, ML = 4 };
+        uint64_t msgs[B * ML] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12}, seeds[B] = {0x1234, 0x1235, 0x1236}, keys[B * 4], keys2[B * 4];
+        const size_t words = lsr_lwe_commitment_words(ctx);
+        CHECK(words == 5 + 3 * 4096);
+        CHECK(strcmp(lsr_lwe_pipeline(ctx), "tile") == 0);
+        uint64_t* rows = (uint64_t*)malloc(B * words * sizeof(uint64_t));
+        int verdicts[B] = {9, 9, 9};
+        CHECK(rows != NULL && lsr_lwe_commit_batch_flat(ctx, msgs, ML, B, seeds, rows) == 0);
+        LweCommitment* single = lwe_commit(ctx, msgs + ML, ML, seeds[1]);
+        CHECK(single != NULL && single->len == words && memcmp(single->data, rows + words, words * sizeof(uint64_t)) == 0);
+        lwe_commitment_free(single);
+        CHECK(rows[0] == 8 * (words - 1));                      /* data[0] = payload byte length, commitment.cpp:44-60 */
+        msgs[2 * ML] ^= 1;                                       /* third claim wrong */
+        CHECK(lsr_lwe_verify_opening_batch_flat(ctx, rows, msgs, ML, B, verdicts) == 0);
+        CHECK(verdicts[0] == 1 && verdicts[1] == 1 && verdicts[2] == 0);
+        msgs[2 * ML] ^= 1;
+        CHECK(lsr_lwe_commit_keys(ctx, msgs, ML, B, seeds, keys) == 0 && lsr_lwe_commit_keys(ctx, msgs, ML, B, seeds, keys2) == 0);
+        CHECK(memcmp(keys, keys2, sizeof keys) == 0);           /* seed != 0: deterministic in (seed, context, message) */
+        seeds[0] = 0;
+        CHECK(lsr_lwe_commit_keys(ctx, msgs, ML, B, seeds, keys2) == 0 && memcmp(keys, keys2, 32) != 0);   /* seed == 0: fresh entropy */
+        free(rows);
+    }
     lwe_context_free(ctx);
 }
 
