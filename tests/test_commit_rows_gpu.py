@@ -253,3 +253,39 @@ def test_table_sizes_around_the_lane_table_limits(pkg, oracle, sigma, n, k, want
         assert np.array_equal(rows[j], oracle.lwe_commit(q, n, k, sigma, KEY, [int(x) for x in msgs[j]], int(seeds[j]))), (sigma, n, k, j)
     assert pkg.verify_openings_words(ctx, rows, msgs) == [1] * batch
     ctx.close()
+
+
+def test_asynchronous_calls_on_one_context_are_ordered(pkg):
+    """The fused pipelines share the context's workspaces, side streams and events, so the library orders asynchronous calls on one
+    context behind each other whatever streams the caller passes (batch.h; round-2 advisor).  Commit on stream A, open the same rows
+    on stream B with no synchronisation in between, twenty times over, then the matrix-vector workload on a third stream: every
+    opening succeeds and the rows never change."""
+    import torch
+    q, n, k, batch, msg_len = 17592182243329, 65536, 2, 70, 5
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+    rng = np.random.default_rng(11)
+    msgs = rng.integers(0, ctx.plain_modulus, size=(batch, msg_len), dtype=np.uint64)
+    seeds = rng.integers(1, 2**63, size=batch, dtype=np.uint64)
+    keys = _keys(ctx, msgs, seeds)
+    d_msgs = torch.from_numpy(msgs.view(np.int64)).cuda()
+    d_keys = torch.from_numpy(keys.view(np.int64)).cuda()
+    words = ctx._lib.lsr_lwe_commitment_words(ctx.handle)
+    want = _rows_device(ctx, msgs, keys)
+    a, b, c3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    d_r = torch.empty((8, k, n), dtype=torch.int64, device="cuda")
+    assert ctx._lib.lsr_fill_splitmix_device(d_r.data_ptr(), 8, k * n, 5, q, torch.cuda.current_stream().cuda_stream) == 0
+    d_e = torch.zeros_like(d_r); d_u = torch.empty_like(d_r); d_u0 = torch.empty_like(d_r)
+    assert ctx._lib.lsr_mlwe_matvec_batch_device(ctx.handle, d_r.data_ptr(), d_e.data_ptr(), d_u0.data_ptr(), 8, None, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    for it in range(20):
+        rows = torch.zeros((batch, words), dtype=torch.int64, device="cuda")
+        res = torch.zeros(batch, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        assert ctx._lib.lsr_lwe_commit_rows_device(ctx.handle, d_msgs.data_ptr(), msg_len, batch, d_keys.data_ptr(), rows.data_ptr(), a.cuda_stream) == 0
+        assert ctx._lib.lsr_lwe_verify_rows_device(ctx.handle, rows.data_ptr(), d_msgs.data_ptr(), msg_len, batch, res.data_ptr(), b.cuda_stream) == 0
+        assert ctx._lib.lsr_mlwe_matvec_batch_device(ctx.handle, d_r.data_ptr(), d_e.data_ptr(), d_u.data_ptr(), 8, None, c3.cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(rows, want), it
+        assert int(res.sum().item()) == batch, it
+        assert torch.equal(d_u, d_u0), it
+    ctx.close()
