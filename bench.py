@@ -404,18 +404,23 @@ def main():
         verdicts = np.zeros(nb, dtype=np.int32)
         flat_lib = pkg._abi.lib()
 
-        def wall(fn, reps=3):
+        def wall(fn, reps=5):
             fn()
-            t0 = time.perf_counter()
+            ts = []
             for _ in range(reps):
+                t0 = time.perf_counter()
                 fn()
-            return (time.perf_counter() - t0) / reps
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts))
 
         t_c = wall(lambda: flat_lib.lsr_lwe_commit_batch_flat(rctx.handle, rmsgs.ctypes.data, 8, nb, rseeds.ctypes.data, rows.ctypes.data))
         t_v = wall(lambda: flat_lib.lsr_lwe_verify_opening_batch_flat(rctx.handle, rows.ctypes.data, rmsgs.ctypes.data, 8, nb, verdicts.ctypes.data))
         extra.update({"ref_params_commits_per_s_pcie": nb / t_c, "ref_params_openings_per_s_pcie": nb / t_v,
                       "ref_params_all_verified": bool((verdicts == 1).all())})
-        # the same two calls with the rows in page-locked host memory (lsr_host_alloc_pinned): the copy back is then one DMA
+        # the same two calls with the rows in page-locked host memory (lsr_host_alloc_pinned): the rows then travel in 32 MiB pieces
+        # under the next piece's kernels.  In a fresh process this leg runs at 497-530 K commitments/s (tools/pin_probe.py); inside
+        # this process, after PyTorch's caching allocator has returned gigabytes to the driver, the same call takes 5.7 ms instead of
+        # 3.9-4.1 (tools/pin_probe2.py reproduces it with nothing but a 2 GiB tensor freed before) — reported as measured
         try:
             pin = pkg.PinnedArray(rows.shape)
             t_cp = wall(lambda: flat_lib.lsr_lwe_commit_batch_flat(rctx.handle, rmsgs.ctypes.data, 8, nb, rseeds.ctypes.data, pin.ptr))
