@@ -50,6 +50,11 @@
 #define LSR_F8_STORE_AUX 2
 #endif
 // matrix loads one component ahead of their products (double-buffered in the registers the round's multipliers vacate)
+// inverse rounds of the tile pipeline: 1 = re-centre register 0 after every inner round (round 3), 0 = round 2's scheme (nothing
+// after rounds 3 and 1, all eight registers after round 2)
+#ifndef LSR_F8_RECENTRE_INNER
+#define LSR_F8_RECENTRE_INNER 1
+#endif
 #ifndef LSR_F8_MAT_AHEAD
 #define LSR_F8_MAT_AHEAD 1
 #endif
@@ -136,9 +141,13 @@ __device__ __forceinline__ void f8_forward_round(double (&v)[kF8Regs], TW&& tw, 
 #pragma unroll
     for (int u = 0; u < 4; ++u) ArithF64::ct(v[2 * u], v[2 * u + 1], tw(3 + u), p);
 }
-// RECENTRE: bring the outputs back to |v| <= q/2.  A round multiplies the bound of the sum outputs by 8, and every
-// product input must stay below 2^50 > 32 q: from q/2 two rounds may pass (4 q, 32 q) before a re-centring.
-template <bool RECENTRE, class TW>
+// RECENTRE = 2: bring every output back to |v| <= q/2 (the last round of a first pass: the strided round that follows runs up to
+// five stages on them).  RECENTRE = 1 (inner rounds, round 3): re-centre only register 0.  Contract between rounds: every input is
+// at most 3.5 q.  Then the input of the product of stage j is a difference of two sums of 2^j inputs, at most 2 * 4 * 3.5 q = 28 q
+// < 2^50 at the top stage, and the all-sum output (register 0) is at most 8 * 3.5 q = 28 q; a product output is at most 0.875 q
+// (=: P) and doubles with every later sum stage: registers 4..7 P, 2..3 2 P, register 1 4 P = 3.5 q — only register 0 can exceed
+// the bound.  (Round 2 re-centred all eight registers every second round: 24 instead of 9 instructions per output and lane.)
+template <int RECENTRE, class TW>
 __device__ __forceinline__ void f8_inverse_round(double (&v)[kF8Regs], TW&& tw, const ModParams& p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) ArithF64::gs(v[2 * u], v[2 * u + 1], tw(3 + u), p);
@@ -153,9 +162,11 @@ __device__ __forceinline__ void f8_inverse_round(double (&v)[kF8Regs], TW&& tw, 
 #pragma unroll
         for (int l = 0; l < 4; ++l) ArithF64::gs(v[l], v[l + 4], w, p);
     }
-    if constexpr (RECENTRE) {
+    if constexpr (RECENTRE == 2) {
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) v[k] = recentre_f64(v[k], p.qd, p.inv_qd);
+    } else if constexpr (RECENTRE == 1) {
+        v[0] = recentre_f64(v[0], p.qd, p.inv_qd);
     }
 }
 
@@ -346,10 +357,10 @@ __device__ __forceinline__ void f8_tile_pipeline(uint32_t tile_pos, Src& src, Si
         double x[kF8Regs];
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) x[k] = recentre_f64(acc[c][k], p.qd, p.inv_qd);
-        f8_inverse_round<false>(x, tw_r3, p);             // |x| <= 4 q
+        f8_inverse_round<LSR_F8_RECENTRE_INNER>(x, tw_r3, p);             // inputs <= q/2; outputs <= 3.5 q
 #if LSR_F8_WAVE_XCHG
         f8_transpose_regs_lanes(x, t);
-        f8_inverse_round<true>(x, tw_r2, p);              // 32 q -> q/2
+        f8_inverse_round<LSR_F8_RECENTRE_INNER == 1 ? 1 : 2>(x, tw_r2, p);
         if constexpr (c > 0) __syncthreads();            // the previous component's last LDS reads are done
 #else
         if constexpr (c > 0) __syncthreads();            // the previous component's last LDS reads are done
@@ -358,21 +369,21 @@ __device__ __forceinline__ void f8_tile_pipeline(uint32_t tile_pos, Src& src, Si
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) x[k] = row2[f8_slot((uint32_t)k << 3)];
-        f8_inverse_round<true>(x, tw_r2, p);              // 32 q -> q/2
+        f8_inverse_round<LSR_F8_RECENTRE_INNER == 1 ? 1 : 2>(x, tw_r2, p);
 #endif
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) row2[f8_slot((uint32_t)k << 3)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) x[k] = row1[f8_slot((uint32_t)k << 6)];
-        f8_inverse_round<false>(x, tw_r1, p);             // 4 q
+        f8_inverse_round<LSR_F8_RECENTRE_INNER>(x, tw_r1, p);
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) row1[f8_slot((uint32_t)k << 6)] = x[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) x[k] = row0[f8_slot((uint32_t)k << 9)];
-        if constexpr (FULL) f8_inverse_round_final(x, tw_r0, cs, p);   // sums up to 32 q enter the n^-1 products: |x| < q
-        else f8_inverse_round<true>(x, tw_r0, p);         // 32 q -> q/2: what the strided round expects
+        if constexpr (FULL) f8_inverse_round_final(x, tw_r0, cs, p);   // sums up to 28 q enter the n^-1 products: |x| < q
+        else f8_inverse_round<2>(x, tw_r0, p);            // -> q/2: what the strided round expects
         sink.store(c, x);
     });
 }
