@@ -271,7 +271,8 @@ static void destroy_lwe_context(LweContext* c) {
         for (int i = 0; i < 8; ++i) secret[i] = 0;
         volatile uint64_t* hk = c->ws_key_host.data();
         for (size_t i = 0; i < c->ws_key_host.size(); ++i) hk[i] = 0;
-        for (lsr::DeviceBuffer<uint64_t>* b : {&c->s_hat, &c->ws_r, &c->ws_e1, &c->ws_e2, &c->ws_keys})
+        // (ws_mid: the fused pipelines' chunk workspace holds transformed commitment randomness between their launches)
+        for (lsr::DeviceBuffer<uint64_t>* b : {&c->s_hat, &c->ws_r, &c->ws_e1, &c->ws_e2, &c->ws_keys, &c->ws_mid})
             if (b->ptr) (void)hipMemset(b->ptr, 0, b->count * 8);
         (void)hipDeviceSynchronize();
         c->a_hat.release(); c->s_hat.release(); c->b_hat.release(); c->cdf.release();

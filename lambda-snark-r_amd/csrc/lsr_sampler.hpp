@@ -73,33 +73,54 @@ __device__ __forceinline__ void cdt_scan(const uint64_t* cdf63, uint32_t entries
 // entry l (63-bit, padded with 2^63 - 1, which is never below u), and a probe is a ds_bpermute_b32 gather — the LDS crossbar, no LDS
 // memory, no banks, so neither the instruction stream nor any memory access pattern depends on the secret words, exactly as in
 // the linear pass.  STEPS = 5 serves tables of <= 32 entries (sigma <= ~3.4: every reference parameter set), STEPS = 6 <= 64
-// entries; a sample costs 3 STEPS VALU + 2 STEPS DS instructions instead of 2 (entries - 1) VALU ones, and the gathers run on the
+// entries; a sample costs about 15 VALU + 10 DS instructions (6-step form: 27 + 22) instead of 2 (entries - 1) VALU ones, and the gathers run on the
 // LDS pipe beside the cipher's VALU work: 209 -> 276 G samples/s with the ChaCha20 stream (tools/ubench_sampler.hip,
 // profiles/r03_ubench_sampler.txt: the cipher alone 327 G/s).  EVERY lane of the wavefront must be active (an inactive source
 // lane reads as zero).  The table is non-decreasing (a cumulative sum), which is all the search needs.
 struct LaneTable {
-    uint32_t lo, hi;
+    uint32_t lo, hi;       // entry l (l = lane % 32), 63-bit, padded with 2^63 - 1
+    uint32_t lo2, hi2;     // entry 32 + l (tables of 33..64 entries; padding otherwise)
 };
 __device__ __forceinline__ uint32_t lane_table_steps(uint32_t entries) { return entries <= 32u ? 5u : (entries <= 64u ? 6u : 0u); }   // 0: use cdt_scan
-// cdf: the 64-bit table (global or LDS); entries: scanned entries (the last one is all ones)
+// cdf: the 64-bit table (global or LDS); entries: scanned entries (the last one is all ones).
+// Every probe reads from lanes 0..31 only: a ds_bpermute whose source lanes l and l + 32 differ lands on one LDS bank twice and takes
+// longer (tools/ubench_sampler.hip: 28.4 against 24.3 cycles for random sources among all 64 lanes, 24.3 for any pattern inside
+// 0..31, broadcasts included), which would make the search time depend on the secret words.  A 64-entry table therefore lives in
+// TWO register pairs of the same 32 lanes, and the 6-step search fetches both candidates and selects.
 __device__ __forceinline__ LaneTable lane_table_load(const uint64_t* cdf, uint32_t entries) {
-    const uint32_t l = threadIdx.x & 63u;
-    const uint64_t c = l < entries ? cdf[l] >> 1 : (~0ull >> 1);
-    return LaneTable{(uint32_t)c, (uint32_t)(c >> 32)};
+    const uint32_t l = threadIdx.x & 31u;
+    const uint64_t a = l < entries ? cdf[l] >> 1 : (~0ull >> 1);
+    const uint64_t b = l + 32u < entries ? cdf[l + 32u] >> 1 : (~0ull >> 1);
+    return LaneTable{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
 }
 template <int STEPS, int COUNT>
 __device__ __forceinline__ void cdt_search(const LaneTable& tab, const uint64_t (&u)[COUNT], uint32_t (&magnitude)[COUNT]) {
+    static_assert(STEPS == 5 || STEPS == 6, "tables of up to 32 or up to 64 entries");
 #pragma unroll
     for (int s = 0; s < COUNT; ++s) {
-        int at = ((1 << (STEPS - 1)) - 1) * 4;              // byte address of the probed lane: (found + step - 1) * 4
+        // STEPS == 6: the first probe is entry 31 for every sample (lane 31, a broadcast); it decides which half of the table the
+        // remaining five steps search
+        bool upper = false;
+        if constexpr (STEPS == 6) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(31 * 4, (int)tab.lo);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(31 * 4, (int)tab.hi);
+            upper = (((uint64_t)hi << 32) | lo) < u[s];
+        }
+        int at = 15 * 4;                                     // byte address of the probed lane: (found + step - 1) * 4
 #pragma unroll
-        for (int step = 1 << (STEPS - 1); step >= 1; step >>= 1) {
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)tab.lo);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)tab.hi);
+        for (int step = 16; step >= 1; step >>= 1) {
+            uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)tab.lo);
+            uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)tab.hi);
+            if constexpr (STEPS == 6) {
+                const uint32_t lo2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)tab.lo2);
+                const uint32_t hi2 = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)tab.hi2);
+                lo = upper ? lo2 : lo;
+                hi = upper ? hi2 : hi;
+            }
             const bool below = (((uint64_t)hi << 32) | lo) < u[s];
             at += step > 1 ? (below ? 2 * step : -2 * step) : (below ? 4 : 0);
         }
-        magnitude[s] = (uint32_t)at >> 2;
+        magnitude[s] = ((uint32_t)at >> 2) + (upper ? 32u : 0u);
     }
 }
 // magnitudes of the eight samples of one stream block, by whichever form the table's size admits (wavefront-uniform choice)

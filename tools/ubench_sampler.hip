@@ -130,7 +130,11 @@ __global__ void __launch_bounds__(256) k_rate(uint64_t* out, uint64_t seed, int 
             else if (OP == 2) a[i] ^= b[i];                                     // v_xor_b32
             else if (OP == 3) a[i] += (x[i] < c) ? 1u : 0u;                     // v_cmp_lt_u64 + v_addc
             else if (OP == 4) a[i] += (b[i] < (uint32_t)c) ? 1u : 0u;           // v_cmp_lt_u32 + v_addc
-            else if (OP == 5) a[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(b[i] & 0xFCu), (int)a[i]);   // ds_bpermute_b32
+            else if (OP == 5) a[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(b[i] & 0xFCu), (int)a[i]) + b[i];   // ds_bpermute_b32, data-dependent lanes
+            else if (OP == 7) a[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(b[i] & 0x04u), (int)a[i]) + b[i];   // every lane reads lane 0 or 1
+            else if (OP == 8) a[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x * 4u) ^ (b[i] & 0x7Cu)) & 0xFCu), (int)a[i]) + b[i];   // a permutation
+            else if (OP == 10) a[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(b[i] & 0x7Cu), (int)a[i]) + b[i];   // random lanes among 0..31 only: distinct banks
+            else if (OP == 9) a[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b[i] & 0x0Cu) | ((threadIdx.x & 1u) << 6)), (int)a[i]) + b[i];   // 64 lanes -> 8 sources
             else if (OP == 6) { a[i] += b[i]; b[i] ^= a[i]; b[i] = (b[i] << 16) | (b[i] >> 16); }   // a ChaCha third: add, xor, rotate
         }
         if (OP == 3 || OP == 4) { for (int i = 0; i < ILP; ++i) { x[i] += a[i]; b[i] += a[i]; } }   // keep the compares loop-variant
@@ -173,12 +177,14 @@ int main() {
     CK(hipMalloc(&d_key, 32)); CK(hipMemcpy(d_key, key, 32, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_cdf, table.size() * 8)); CK(hipMemcpy(d_cdf, table.data(), table.size() * 8, hipMemcpyHostToDevice));
     const int iters = 256;
-    static const char* rate_names[] = {"v_add_u32", "v_alignbit_b32", "v_xor_b32", "v_cmp_lt_u64 + v_addc", "v_cmp_lt_u32 + v_addc", "ds_bpermute_b32", "add+xor+rot (3 ops)"};
+    static const char* rate_names[] = {"v_add_u32", "v_alignbit_b32", "v_xor_b32", "v_cmp_lt_u64 + v_addc", "v_cmp_lt_u32 + v_addc", "ds_bpermute_b32 (random lanes)",
+                                       "add+xor+rot (3 ops)", "ds_bpermute_b32 (2 source lanes)", "ds_bpermute_b32 (a permutation)", "ds_bpermute_b32 (8 source lanes)",
+                                       "ds_bpermute_b32 (random lanes 0..31)"};
     static const char* mode_names[] = {"cipher only (8 samples/unit)", "cipher + library scan", "library scan only", "borrow-chain scan only", "bpermute scan only",
                                        "hi32 scan only (rate probe)", "cipher + borrow scan", "cipher + bpermute scan"};
     for (int bpc : {1, 2, 4, 8}) {
-#define RATE(OP) if (timeit(rate_names[OP], 8.0 * 2048, bpc, [&](int g) { hipLaunchKernelGGL(k_rate<OP>, dim3(g), dim3(256), 0, 0, d_out, 12345ull, 2048); })) return 1;
-        RATE(0) RATE(1) RATE(2) RATE(3) RATE(4) RATE(5) RATE(6)
+#define RATE(OP) if (timeit(rate_names[OP], 8.0 * 8192, bpc, [&](int g) { hipLaunchKernelGGL(k_rate<OP>, dim3(g), dim3(256), 0, 0, d_out, 12345ull, 8192); })) return 1;
+        RATE(0) RATE(1) RATE(2) RATE(3) RATE(4) RATE(5) RATE(6) RATE(7) RATE(8) RATE(9) RATE(10)
 #define MODE(M) if (timeit(mode_names[M], 8.0 * iters, bpc, [&](int g) { hipLaunchKernelGGL(k_sampler<M>, dim3(g), dim3(256), 0, 0, d_out, d_key, d_cdf, entries, iters); })) return 1;
         MODE(0) MODE(1) MODE(2) MODE(3) MODE(4) MODE(5) MODE(6) MODE(7)
         printf("\n");
