@@ -884,13 +884,14 @@ static void verify_host_rows(const LweContext& c, const uint64_t* rows, const ui
     const size_t row = kHeaderWords + ((size_t)c.k + 1) * c.n;
     const size_t chunk = verify_chunk(c, count);
     if (c.ws_rows.count < chunk * row) c.ws_rows.allocate(chunk * row);
-    DeviceBuffer<uint64_t> d_msgs(chunk * msg_len);
+    ensure_input_space(c, chunk);                            // ws_dm: chunk x n message slots (msg_len <= n here), no allocation per call
+    uint64_t* const d_msgs = c.ws_dm.ptr;
     std::vector<unsigned long long> state(chunk + (chunk + 1) / 2);
     for (size_t first = 0; first < count; first += chunk) {
         const size_t now = std::min(chunk, count - first);
         LSR_HIP(hipMemcpyAsync(c.ws_rows.ptr, rows + first * row, now * row * 8, hipMemcpyHostToDevice, s));
-        LSR_HIP(hipMemcpyAsync(d_msgs.ptr, messages + first * msg_len, now * msg_len * 8, hipMemcpyHostToDevice, s));
-        verify_rows_device(c, c.ws_rows.ptr, d_msgs.ptr, msg_len, now, s);
+        LSR_HIP(hipMemcpyAsync(d_msgs, messages + first * msg_len, now * msg_len * 8, hipMemcpyHostToDevice, s));
+        verify_rows_device(c, c.ws_rows.ptr, d_msgs, msg_len, now, s);
         LSR_HIP(hipMemcpyAsync(state.data(), c.ws_vflags.ptr, (now + (now + 1) / 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         LSR_HIP(hipStreamSynchronize(s));
         const uint32_t* const host_bad = reinterpret_cast<const uint32_t*>(state.data() + now);

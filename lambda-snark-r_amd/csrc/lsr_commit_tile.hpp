@@ -31,7 +31,14 @@ __device__ __forceinline__ uint64_t div128_by_q(uint64_t hi, uint64_t lo, const 
     carry += s2 < s;
     uint64_t quot = hi * p.barrett_hi + m1_hi + m2_hi + carry;
     uint64_t rem = lo - quot * p.q;
-    while (rem >= p.q) { rem -= p.q; ++quot; }
+    // the estimate drops at most three partial carries: three branch-free corrections (no data-dependent trip count: the dividend
+    // is t (v - <s, u>), and the opening check is meant to be constant-time, commitment.h:92)
+#pragma unroll
+    for (int fix = 0; fix < 3; ++fix) {
+        const bool over = rem >= p.q;
+        rem -= over ? p.q : 0;
+        quot += over ? 1 : 0;
+    }
     return quot;
 }
 // round(t w / q) mod t for a canonical residue w: the plaintext slot an opening decodes (commitment.cpp:215-218 via SEAL decrypt).
