@@ -13,6 +13,7 @@
 //   combine : sum_i (c_i mod t) (u_i, v_i)
 // Wire format: data[0] = payload bytes; payload = {"LSRC0001", n | k<<32, q, t, u[k][n], v[n]}.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -527,10 +528,10 @@ static void ensure_host_stage(const LweContext& c, size_t words) {
 }
 
 static LweCommitment* new_commitment(size_t words) {
-    auto* out = new LweCommitment;
+    std::unique_ptr<LweCommitment> out(new LweCommitment);
     out->len = words;
     out->data = new uint64_t[words];
-    return out;
+    return out.release();
 }
 
 // The per-commitment stream keys and the messages of a batch, staged on the device (enqueued on `s`).
@@ -760,31 +761,37 @@ static void commit_chunk(const LweContext& c, const uint64_t* messages, size_t m
     ensure_host_stage(c, batch * words);
     LSR_HIP(hipMemcpyAsync(c.host_stage, c.ws_rows.ptr, batch * words * 8, hipMemcpyDeviceToHost, s));
     std::vector<LweCommitment*> made(batch, nullptr);
-    try {
-        for (size_t j = 0; j < batch; ++j) made[j] = new_commitment(words);   // overlaps the copy
-        LSR_HIP(hipStreamSynchronize(s));
-    } catch (...) {
-        (void)hipStreamSynchronize(s);
+    const size_t workers = std::min<size_t>(8, std::max<size_t>(1, (batch * words * 8) >> 22));   // one thread per ~4 MiB, at most 8
+    const size_t per = (batch + workers - 1) / workers;
+    auto in_parallel = [&](auto&& body) {                   // body(lo, hi) over disjoint slices of the batch
+        if (workers <= 1) { body(size_t(0), batch); return; }
+        std::vector<std::thread> pool;
+        for (size_t w = 0; w < workers; ++w) {
+            const size_t lo = w * per, hi = std::min(batch, lo + per);
+            if (lo < hi) pool.emplace_back(body, lo, hi);
+        }
+        for (std::thread& th : pool) th.join();
+    };
+    // the allocations (98 KB each at the reference's parameters, first touch included) overlap the copy and each other
+    std::atomic<bool> failed{false};
+    in_parallel([&](size_t lo, size_t hi) {
+        try {
+            for (size_t j = lo; j < hi; ++j) made[j] = new_commitment(words);
+        } catch (...) {
+            failed = true;
+        }
+    });
+    const hipError_t synced = hipStreamSynchronize(s);
+    if (failed || synced != hipSuccess) {
         for (LweCommitment* m : made) {
             if (m) { delete[] m->data; delete m; }
         }
-        throw;
+        if (failed) throw std::bad_alloc();
+        throw HipFailure(std::string("hipStreamSynchronize: ") + hipGetErrorString(synced));
     }
-    auto fill = [&](size_t lo, size_t hi) {
+    in_parallel([&](size_t lo, size_t hi) {
         for (size_t j = lo; j < hi; ++j) std::memcpy(made[j]->data, c.host_stage + j * words, words * 8);
-    };
-    const size_t workers = std::min<size_t>(8, std::max<size_t>(1, (batch * words * 8) >> 22));   // one thread per ~4 MiB, at most 8
-    if (workers <= 1) {
-        fill(0, batch);
-    } else {
-        std::vector<std::thread> pool;
-        const size_t per = (batch + workers - 1) / workers;
-        for (size_t w = 0; w < workers; ++w) {
-            const size_t lo = w * per, hi = std::min(batch, lo + per);
-            if (lo < hi) pool.emplace_back(fill, lo, hi);
-        }
-        for (std::thread& th : pool) th.join();
-    }
+    });
     for (size_t j = 0; j < batch; ++j) out[j] = made[j];
 }
 
@@ -948,9 +955,24 @@ static void verify_opening_batch(const LweContext& c, const LweCommitment* const
     std::vector<int> part(chunk);
     for (size_t first = 0; first < live.size(); first += chunk) {
         const size_t now = std::min(chunk, live.size() - first);
-        for (size_t j = 0; j < now; ++j) {
-            std::memcpy(h_rows + j * row, cms[live[first + j]]->data, row * 8);
-            std::memcpy(h_msgs + j * msg_len, messages + live[first + j] * msg_len, msg_len * 8);
+        // the gather is a plain host copy of `now` rows (98 KB each at the reference's parameters): a few threads, one per ~4 MiB
+        auto gather = [&](size_t lo, size_t hi) {
+            for (size_t j = lo; j < hi; ++j) {
+                std::memcpy(h_rows + j * row, cms[live[first + j]]->data, row * 8);
+                std::memcpy(h_msgs + j * msg_len, messages + live[first + j] * msg_len, msg_len * 8);
+            }
+        };
+        const size_t workers = std::min<size_t>(8, std::max<size_t>(1, (now * row * 8) >> 22));
+        if (workers <= 1) {
+            gather(0, now);
+        } else {
+            std::vector<std::thread> pool;
+            const size_t per = (now + workers - 1) / workers;
+            for (size_t w = 0; w < workers; ++w) {
+                const size_t lo = w * per, hi = std::min(now, lo + per);
+                if (lo < hi) pool.emplace_back(gather, lo, hi);
+            }
+            for (std::thread& th : pool) th.join();
         }
         verify_host_rows(c, h_rows, h_msgs, msg_len, now, part.data(), s);
         for (size_t j = 0; j < now; ++j) results[live[first + j]] = part[j];
