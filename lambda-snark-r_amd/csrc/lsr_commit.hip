@@ -7,7 +7,7 @@
 //   commit  : r, e1 <- chi^k, e2 <- chi from the ChaCha20 streams of a per-commitment 256-bit key:
 //             PRF(seed, context id, embedded message) for seed != 0, OS entropy for seed == 0 (lsr_keys.hpp)
 //             u = INTT(A_hat^T r_hat) + e1                 (the matrix–vector + blinding-add workload)
-//             v = INTT(<b_hat, r_hat>) + e2 + Delta (m mod t)
+//             v = INTT(<b_hat, r_hat>) + e2 + round(q (m mod t) / t)      (why not floor(q/t) m)
 //   verify  : round(t/q (v - <s,u>)) mod t == m, word for word (commitment.cpp:223-226: decoded ^ message, no reduction of
 //             the claimed message: a word >= t never opens)
 //   combine : sum_i (c_i mod t) (u_i, v_i)
@@ -202,7 +202,7 @@ static LweContext* create_lwe_context(const PublicParams* params, uint64_t key_s
     c->tuning.mixed = env_flag("LAMBDA_SNARK_COMMIT_MIXED", true);
     c->params = *params;
     c->q = q; c->t = t; c->delta = q / t; c->n = n; c->k = k; c->sigma = params->sigma;
-    // Noise budget: opening decodes round(t/q (Delta m + <e,r> - <s,e1> + e2)); the noise term is a sum of 2 k n products of
+    // Noise budget: opening decodes round(t/q (round(q m / t) + <e,r> - <s,e1> + e2)); the noise term is a sum of 2 k n products of
     // two sigma-Gaussians, standard deviation sigma^2 sqrt(2 k n); with an 8-sigma tail it must stay below Delta / 2.
     // A context whose FRESH commitments could fail to verify is refused here instead of failing silently later.
     c->noise_unit = 8.0 * std::sqrt(2.0 * k * n) * params->sigma * params->sigma;
@@ -589,7 +589,7 @@ static void commit_rows_general(const LweContext& c, const uint64_t* d_msgs, siz
     launch_gaussian3(GaussianJob{c.ws_r.ptr, d_keys, 0, k, kDomR, n, batch * k, c.q}, GaussianJob{c.ws_e1.ptr, d_keys, 0, k, kDomE1, n, batch * k, c.q},
                      GaussianJob{c.ws_e2.ptr, d_keys, 0, 1, kDomE2, n, batch, c.q}, c.cdf.ptr, c.cdf_entries, s);
     mlwe_matvec_device(c, c.ws_r.ptr, c.ws_e1.ptr, c.ws_u.ptr, batch, s);    // leaves r_hat in ws_r
-    // v = INTT(<b_hat, r_hat>) + e2 + Delta m
+    // v = INTT(<b_hat, r_hat>) + e2 + round(q m / t)
     matvec(c, c.ws_v.ptr, c.b_hat.ptr, c.ws_r.ptr, nullptr, 1, k, 0, 1, batch, s);
     launch_ntt(*c.ntt, c.ws_v.ptr, batch, true, s);
     const uint64_t vcount = (uint64_t)batch * n;
@@ -613,7 +613,7 @@ static void commit_rows_tile(const LweContext& c, const uint64_t* d_msgs, size_t
     for (size_t first = 0; first < batch; first += 0x40000000u) {            // grid limit: 2^30 workgroups per launch
         const size_t now = std::min<size_t>(batch - first, 0x40000000u);
         const CommitTileJob job{d_rows + first * row_words, d_keys + 4 * first, d_msgs + first * msg_len, (uint64_t)msg_len, (uint64_t)std::min<size_t>(msg_len, c.n),
-                                c.cdf.ptr, c.cdf_entries, (uint32_t)now, c.q, c.t, c.delta};
+                                c.cdf.ptr, c.cdf_entries, (uint32_t)now, c.q, c.t};
         switch (c.k) {
             case 1: launch_commit_tile<1>(c, job, s); break;
             case 2: launch_commit_tile<2>(c, job, s); break;
@@ -652,7 +652,7 @@ static void commit_rows_fused(const LweContext& c, const uint64_t* d_msgs, size_
         uint64_t* const ws = c.ws_mid.ptr + (index % streams) * slot_words;
         uint64_t* const rows = d_rows + first * row_words;
         const CommitTopJob job{rows, ws, d_keys + 4 * first, d_msgs + first * msg_len, (uint64_t)msg_len, (uint64_t)std::min<size_t>(msg_len, n), c.cdf.ptr,
-                               c.cdf_entries, (uint32_t)now, k, (uint64_t)row_words, c.q, c.t, c.delta};
+                               c.cdf_entries, (uint32_t)now, k, (uint64_t)row_words, c.q, c.t};
         const unsigned grid_f = static_cast<unsigned>((now * k << c.logn) >> (r + 8)), grid_i = static_cast<unsigned>((now * (k + 1) << c.logn) >> (r + 8));
         if (r == 4) hipLaunchKernelGGL((commit_top_forward_kernel<4>), dim3(grid_f), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
         else hipLaunchKernelGGL((commit_top_forward_kernel<5>), dim3(grid_f), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
@@ -1008,7 +1008,7 @@ static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** 
     uint64_t* const h_terms = c.host_stage;
     uint64_t* const h_coeffs = c.host_stage + group * body_words;
     LSR_HIP(hipMemsetAsync(acc.ptr, 0, body_words * 8, s));
-    // noise budget of the result: sum_i (c_i mod t) fresh-commitment noises must still decode (8-sigma tail below Delta / 2).
+    // noise budget of the result: sum_i |c_i| (centred mod t) fresh-commitment noises must still decode (8-sigma tail below Delta / 2).
     // The reference's 72-bit SEAL modulus absorbs any c_i < t (commitment.cpp:88-96,247-266); a 44-bit modulus does not, and a
     // commitment that cannot open is refused here rather than returned.  A 60-bit NTT prime as params->modulus gives the
     // reference's range.

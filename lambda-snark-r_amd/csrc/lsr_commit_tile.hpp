@@ -114,7 +114,7 @@ struct CommitTileJob {
     const uint64_t* cdf;         // CDT table (64-bit thresholds)
     uint32_t entries;            // scanned entries (<= 64)
     uint32_t batch;
-    uint64_t q, t, delta;
+    uint64_t q, t;
 };
 
 // r_i sampled where the forward transform wants it
@@ -132,7 +132,7 @@ struct CommitTileSource {
     }
     __device__ __forceinline__ uint32_t ahead(int) const { return 0; }
 };
-// u_c = . + e1_c,  v = . + e2 + Delta (m mod t): canonical words into the wire row
+// u_c = . + e1_c,  v = . + e2 + round(q (m mod t) / t): canonical words into the wire row
 template <int K>
 struct CommitTileSink {
     const CommitTileJob& job;
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(kF8Threads, 4) verify_tile_kernel(VerifyTileJo
 // The same two operations at n = 2^16 / 2^17 (a polynomial is 16 / 32 tiles): three launches per chunk of commitments,
 //     commit_top_forward  — r_i SAMPLED where the top forward round wants its operands (no array of r exists), raw elements out
 //     mlwe_mid_general    — tile pipeline: 12 forward stages, [A^T | b_hat] product, 12 inverse stages, into the wire rows (raw)
-//     commit_top_inverse  — top inverse round in place on the rows, + e1_c / + e2 + Delta (m mod t) sampled in the pass, canonical
+//     commit_top_inverse  — top inverse round in place on the rows, + e1_c / + e2 + round(q (m mod t) / t), the blinding sampled in the pass, canonical
 // (rank 4: the scalar component is a second, one-column pass of the middle stage — five accumulators do not fit its 128 VGPRs).
 // A workgroup of the outer rounds owns 256 columns x 2^R rows of one polynomial = 2^R * 32 stream blocks of 8 consecutive
 // coefficients, 2^R / 8 per lane; the samples change hands through an int16 tile in LDS.
@@ -336,7 +336,7 @@ struct CommitTopJob {
     const uint64_t* cdf;
     uint32_t entries, vectors, k;
     uint64_t row_words;
-    uint64_t q, t, delta;
+    uint64_t q, t;
 };
 
 template <int R>
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(256) commit_top_inverse_kernel(CommitTopJob jo
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = __longlong_as_double((long long)__builtin_nontemporal_load(data + ((size_t)k << lo)));   // in flight under the cipher
     const LaneTable tab = lane_table_load(job.cdf, job.entries);
-    const bool scalar = c == job.k;                                    // v = . + e2 + Delta (m mod t); the others u_c = . + e1_c
+    const bool scalar = c == job.k;                                    // v = . + e2 + round(q (m mod t) / t); the others u_c = . + e1_c
     top_round_sample<R>(tile, job.keys + 4 * (size_t)j, scalar ? kDomE2 : kDomE1, scalar ? 0u : c, lo, low0, tab, job.entries);
     __syncthreads();
     top_round_inverse<R>(v, tw, cs, p);
