@@ -169,6 +169,39 @@ class LweContext:
     def module_rank(self):
         return self._lib.lsr_lwe_module_rank(self._h)
 
+    @property
+    def pipeline(self):
+        """``lsr_lwe_pipeline``: which kernels this context's commitments and openings run on ("tile", "fused", "fused-matvec", "general")."""
+        return self._lib.lsr_lwe_pipeline(self._h).decode()
+
+    @property
+    def commitment_words(self):
+        return self._lib.lsr_lwe_commitment_words(self._h)
+
+    def commit_keys(self, messages, seeds):
+        """``lsr_lwe_commit_keys``: the per-commitment 256-bit stream keys exactly as ``lwe_commit`` derives them (seed 0: fresh entropy),
+        [batch][4] uint64 — the input of the device-resident ``lsr_lwe_commit_rows_device``."""
+        messages = np.ascontiguousarray(messages, dtype=np.uint64)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        if messages.ndim != 2 or messages.shape[0] != seeds.size:
+            raise ValueError("messages must be [batch][msg_len] with one seed per row")
+        keys = np.zeros((seeds.size, 4), dtype=np.uint64)
+        rc = self._lib.lsr_lwe_commit_keys(self._h, messages.ctypes.data if messages.size else None, messages.shape[1], seeds.size, seeds.ctypes.data,
+                                           keys.ctypes.data)
+        if rc != 0:
+            raise CoreError("lsr_lwe_commit_keys failed: " + _abi.last_error())
+        return keys
+
+    def commit_rows_device(self, d_messages, msg_len, batch, d_keys, d_rows, stream):
+        """``lsr_lwe_commit_rows_device``: device pointers (ints) in, wire rows out, asynchronous on `stream`."""
+        if self._lib.lsr_lwe_commit_rows_device(self._h, d_messages, msg_len, batch, d_keys, d_rows, stream) != 0:
+            raise CoreError("CommitmentFailed: " + _abi.last_error())
+
+    def verify_rows_device(self, d_rows, d_messages, msg_len, count, d_results, stream):
+        """``lsr_lwe_verify_rows_device``: int32 verdicts (1 / 0 / -1 as ``lwe_verify_opening``) per row, asynchronous on `stream`."""
+        if self._lib.lsr_lwe_verify_rows_device(self._h, d_rows, d_messages, msg_len, count, d_results, stream) != 0:
+            raise CoreError("VerificationFailed: " + _abi.last_error())
+
     def public_matrix(self):
         k, n = self.module_rank, self.ring_degree
         a = np.zeros((k, k, n), dtype=np.uint64)

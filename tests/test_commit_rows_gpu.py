@@ -14,14 +14,11 @@ SIGMA = 3.19
 
 
 def _pipeline(ctx):
-    return ctx._lib.lsr_lwe_pipeline(ctx.handle).decode()
+    return ctx.pipeline
 
 
 def _keys(ctx, msgs, seeds):
-    msgs = np.ascontiguousarray(msgs, dtype=np.uint64)
-    out = np.zeros((len(seeds), 4), dtype=np.uint64)
-    assert ctx._lib.lsr_lwe_commit_keys(ctx.handle, msgs.ctypes.data if msgs.size else None, msgs.shape[1], len(seeds), seeds.ctypes.data, out.ctypes.data) == 0
-    return out
+    return ctx.commit_keys(msgs, seeds)
 
 
 def _rows_device(ctx, msgs, keys, stream=None):
@@ -33,7 +30,8 @@ def _rows_device(ctx, msgs, keys, stream=None):
     d_keys = torch.from_numpy(keys.view(np.int64)).cuda()
     d_rows = torch.zeros((batch, words), dtype=torch.int64, device="cuda")
     s = torch.cuda.current_stream().cuda_stream if stream is None else stream
-    assert ctx._lib.lsr_lwe_commit_rows_device(ctx.handle, d_msgs.data_ptr() if msg_len else None, msg_len, batch, d_keys.data_ptr(), d_rows.data_ptr(), s) == 0
+    assert words == ctx.commitment_words
+    ctx.commit_rows_device(d_msgs.data_ptr() if msg_len else None, msg_len, batch, d_keys.data_ptr(), d_rows.data_ptr(), s)
     torch.cuda.synchronize()
     return d_rows
 
