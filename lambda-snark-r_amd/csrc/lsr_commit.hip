@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <new>
 #include <thread>
@@ -538,6 +539,35 @@ static LweCommitment* new_commitment(size_t words) {
 // Host prep (lsr_keys.hpp): seed == 0 => 256 bits of fresh entropy (commitment.h:52), else PRF(seed, context id, embedded message)
 // — a reused seed never repeats the blinding across messages or contexts.  Only the first `copy` slots of each message matter
 // (commitment.cpp:146-149); rows keep their msg_len pitch.
+// keys[j][4] of `batch` commitments (lsr_keys.hpp).  The PRF runs over the embedded message (two multiplications mod 2^61 - 1 per
+// slot), so a batch of full-length messages costs the host about 10 us per commitment on one core — more than the GPU spends on it;
+// batches above ~0.5 M message words are split over up to eight threads (the derivation is a pure function of its inputs)
+static void derive_commit_keys(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, uint64_t* keys) {
+    const size_t copy = std::min<size_t>(msg_len, c.n);
+    auto slice = [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+            const StreamKey key = seeds && seeds[j] ? derive_commit_key(seeds[j], c.keys.id, messages + j * msg_len, copy, c.t) : fresh_key();
+            key_words(key, keys + 4 * j);
+        }
+    };
+    const size_t work = batch * (copy + 64);
+    const size_t workers = std::min<size_t>(8, std::max<size_t>(1, work >> 19));
+    if (workers <= 1 || batch < 2 * workers) { slice(0, batch); return; }
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> errors(workers);
+    const size_t per = (batch + workers - 1) / workers;
+    for (size_t w = 0; w < workers; ++w) {
+        const size_t lo = w * per, hi = std::min(batch, lo + per);
+        if (lo < hi)
+            pool.emplace_back([&, w, lo, hi] {
+                try { slice(lo, hi); } catch (...) { errors[w] = std::current_exception(); }     // e.g. the OS entropy source failing
+            });
+    }
+    for (std::thread& th : pool) th.join();
+    for (const std::exception_ptr& e : errors)
+        if (e) std::rethrow_exception(e);
+}
+
 struct StagedInputs {
     const uint64_t* d_keys = nullptr;
     const uint64_t* d_msgs = nullptr;
@@ -549,10 +579,7 @@ static void stage_commit_inputs(const LweContext& c, const uint64_t* messages, s
     std::vector<uint64_t>& key_host = c.ws_key_host;
     key_host.resize(batch * 4);
     const size_t copy = std::min<size_t>(msg_len, c.n);
-    for (size_t j = 0; j < batch; ++j) {
-        const StreamKey key = seeds && seeds[j] ? derive_commit_key(seeds[j], c.keys.id, messages + j * msg_len, copy, c.t) : fresh_key();
-        key_words(key, key_host.data() + 4 * j);
-    }
+    derive_commit_keys(c, messages, msg_len, batch, seeds, key_host.data());
     const size_t in_words = batch * 4 + (copy ? batch * msg_len : 0);
     if (in_words <= LweContext::kSmallInWords) {
         // one upload from page-locked memory instead of two staged ones (every caller synchronises the stream before it returns, so
@@ -1245,11 +1272,7 @@ int lsr_lwe_commit_batch_flat_device(LweContext* ctx, const uint64_t* messages, 
 int lsr_lwe_commit_keys(const LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, uint64_t* out_keys) noexcept {
     if (!ctx || !out_keys || (!messages && msg_len)) return -1;
     try {
-        const size_t copy = std::min<size_t>(msg_len, ctx->n);
-        for (size_t j = 0; j < batch; ++j) {
-            const lsr::StreamKey key = seeds && seeds[j] ? lsr::derive_commit_key(seeds[j], ctx->keys.id, messages + j * msg_len, copy, ctx->t) : lsr::fresh_key();
-            lsr::key_words(key, out_keys + 4 * j);
-        }
+        lsr::derive_commit_keys(*ctx, messages, msg_len, batch, seeds, out_keys);
         return 0;
     } catch (const std::exception& e) {
         lsr::set_last_error(std::string("lsr_lwe_commit_keys: ") + e.what());
