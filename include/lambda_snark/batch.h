@@ -24,7 +24,7 @@ extern "C" {
 int lsr_device_count(void) LSR_NOEXCEPT;
 /* last error message of the calling thread ("" if none) */
 const char* lsr_last_error(void) LSR_NOEXCEPT;
-/* library / kernel-variant description, e.g. "lambda_snark_core hip gfx950 v1" */
+/* library / kernel-variant description, e.g. "lambda_snark_core hip gfx950 r3 (...)" */
 const char* lsr_version(void) LSR_NOEXCEPT;
 
 /* ---------------- NTT: contexts on a chosen device ---------------- */
@@ -91,7 +91,9 @@ int lsr_lwe_commit_batch_flat(LweContext* ctx, const uint64_t* messages, size_t 
 int lsr_lwe_commit_batch_flat_device(LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch,
                                      const uint64_t* seeds, uint64_t* d_out_words) LSR_NOEXCEPT;
 
-/* Whole commitments without a byte of host traffic (round 3).  lsr_lwe_commit_keys derives, on the host, the per-commitment
+/* Whole commitments without a byte of host traffic (round 3): the batched, device-resident form of lwe_commit
+ * (cpp-core/src/commitment.cpp:138-164, contract cpp-core/include/lambda_snark/commitment.h:43-63) and of lwe_verify_opening
+ * (commitment.cpp:200-232, commitment.h:80-99).  lsr_lwe_commit_keys derives, on the host, the per-commitment
  * 256-bit stream keys exactly as lwe_commit does (seed != 0: PRF of seed, context id and embedded message; seed == 0: fresh OS
  * entropy) into out_keys[batch][4]; lsr_lwe_commit_rows_device then turns DEVICE arrays d_keys[batch][4] and
  * d_messages[batch][msg_len] into the wire rows d_rows[batch][lsr_lwe_commitment_words(ctx)] — word for word what

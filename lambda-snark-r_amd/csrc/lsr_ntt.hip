@@ -533,7 +533,7 @@ extern "C" {
 
 int lsr_device_count(void) noexcept { return lsr::visible_device_count(); }
 const char* lsr_last_error(void) noexcept { return lsr::last_error_cstr(); }
-const char* lsr_version(void) noexcept { return "lambda_snark_core hip gfx950 r1 (f64-FMA Barrett + u64 Shoup NTT)"; }
+const char* lsr_version(void) noexcept { return "lambda_snark_core hip gfx950 r3 (f64-FMA Barrett + u64 Shoup NTT; fused tile pipeline for commitments and openings)"; }
 void lsr_set_arith_mode(int mode) noexcept { lsr::g_arith_mode.store(mode); }
 
 NttContext* ntt_context_create(uint64_t q, uint32_t n) noexcept {
