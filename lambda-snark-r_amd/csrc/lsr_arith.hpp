@@ -275,7 +275,9 @@ struct ArithGold {
     using twid = uint64_t;   // Montgomery form
 
     static __device__ __forceinline__ elem load(uint64_t x, const ModParams&) { return x >= kGoldilocks ? x - kGoldilocks : x; }
-    static __device__ __forceinline__ uint64_t store_canonical(elem v, const ModParams&) { return v; }
+    // forward (Cooley–Tukey) values are LAZY: any 64-bit representative (round 3, see ct below); one conditional subtraction
+    // canonicalises, since 2^64 < 2 p
+    static __device__ __forceinline__ uint64_t store_canonical(elem v, const ModParams&) { return v >= kGoldilocks ? v - kGoldilocks : v; }
     static __device__ __forceinline__ uint64_t store_reduced(elem v, const ModParams&) { return v; }
     static __device__ __forceinline__ uint64_t store_reduced_plus(elem v, uint64_t e, const ModParams&) {
         return gold_add(v, e >= kGoldilocks ? e - kGoldilocks : e);
@@ -291,10 +293,19 @@ struct ArithGold {
             for (int u = 0; u < COUNT; u += 2) buf_load128(table, idx * 8u, (uint32_t)u * 8u, out[u], out[u + 1]);
         }
     }
+    // Cooley–Tukey with LAZY sums: x may be any 64-bit representative, the product t is canonical (gold_mul_mont takes any
+    // 64-bit multiplicand).  a + t wraps at most once (t < p), and the wrapped sum a + t - 2^64 < p - 1 leaves room for the
+    // correction + (2^32 - 1) = + 2^64 mod p; a - t borrows at most once, and the wrapped difference a - t + 2^64 > 2^64 - p =
+    // 2^32 - 2 leaves room for - (2^32 - 1).  No comparison with p, no second correction: 110 instead of 123 cycles per
+    // wave-butterfly in tools/ubench_arith ("goldilocks mont lazy").  The inverse (Gentleman–Sande) butterflies add two lazy values
+    // and stay canonical.
     static __device__ __forceinline__ void ct(elem& x, elem& y, twid w, const ModParams&) {
         const uint64_t t = gold_mul_mont(y, w), a = x;
-        x = gold_add(a, t);
-        y = gold_sub(a, t);
+        unsigned long long s, d;
+        const bool carry = __builtin_uaddll_overflow(a, t, &s);
+        const bool borrow = __builtin_usubll_overflow(a, t, &d);
+        x = s + (carry ? kGoldEpsilon : 0ull);
+        y = d - (borrow ? kGoldEpsilon : 0ull);
     }
     static __device__ __forceinline__ void gs(elem& x, elem& y, twid w, const ModParams&) {
         const uint64_t a = x, b = y;

@@ -374,7 +374,8 @@ void launch_ntt(const NttContext& c, uint64_t* d, size_t batch, bool inverse, hi
 }
 
 // Forward transform of a Goldilocks batch (n <= 4096: one tile launch) with elementwise work of the prover's quotient pipeline
-// fused into its read-in (lsr_ntt_kernels.hpp, FuseIn): mode 1 = operands multiplied by x1 first, mode 2 = a b == c tested on the way in.
+// fused into its read-in (lsr_ntt_kernels.hpp, FuseIn): mode 1 = operands multiplied by x1 first, mode 2 = a b == c tested on the way in,
+// mode 3 = mode 1 plus the quotient's finish on the way out (launch_ntt_forward_finish below).
 template <int MODE>
 static void fused_forward(const NttContext& c, uint64_t* d, size_t total, hipStream_t s, const uint64_t* src, const FuseIn& fuse) {
     const unsigned grid = static_cast<unsigned>((total + kTile - 1) / kTile);
@@ -396,6 +397,24 @@ void launch_ntt_forward_fused(const NttContext& c, uint64_t* d, size_t batch, hi
     if (!total) return;
     if (mode == 1) fused_forward<1>(c, d, total, s, src, FuseIn{x1, nullptr, nullptr});
     else fused_forward<2>(c, d, total, s, src, FuseIn{x1, x2, bad});
+    LSR_HIP(hipGetLastError());
+}
+
+// Last transform of the quotient pipeline with both neighbours folded in: (d x1) on the way in, Q = (2m)^-1 c_hat - untwist z in natural
+// order (and the per-instance degree bound `top`) on the way out; d is read only, z is never stored.
+void launch_ntt_forward_finish(const NttContext& c, const uint64_t* d, size_t batch, hipStream_t s, const uint64_t* x1, const uint64_t* chat,
+                               const uint64_t* untwist, uint64_t half_m_inv, uint64_t* quotient, uint32_t* top) {
+    if (!ntt_forward_can_fuse(c) || !d || !x1 || !chat || !untwist || !quotient || !top)
+        throw std::runtime_error("fused forward transform with finish: Goldilocks context with n <= 4096 and every operand");
+    const size_t total = batch << c.logn;
+    if (!total) return;
+    FuseIn fuse{x1, nullptr, nullptr};
+    fuse.chat = chat;
+    fuse.untwist = untwist;
+    fuse.half_m_inv = half_m_inv;
+    fuse.quotient = quotient;
+    fuse.top = top;
+    fused_forward<3>(c, const_cast<uint64_t*>(d), total, s, nullptr, fuse);
     LSR_HIP(hipGetLastError());
 }
 

@@ -174,10 +174,20 @@ __device__ __forceinline__ void inverse_round(typename A::elem (&v)[kRegs], cons
 //   MODE 1: every operand is first multiplied by the word of `x1` at the same index (standard form) — the coset product a b;
 //   MODE 2: the operands are the c_k of R1CS constraints and x1 = a, x2 = b: a_k b_k == c_k is tested on the way in, a failing
 //           constraint marks its instance in `bad` (is_satisfied, r1cs.rs:148-172).  The transform itself is unchanged.
+//   MODE 3: MODE 1 on the way in, and on the way OUT the finish of the quotient pipeline (lsr_prover.hip step 6): the transform's
+//           output z never reaches memory; Q[j] = (2m)^-1 c_hat[p] - psi^-j (2m)^-1 z[p], p = bitrev(j), is formed where the last round
+//           leaves z in registers (c_hat and the untwist table read at the same indices), scattered to its natural-order slot of the
+//           LDS tile and streamed out coalesced, with the per-instance highest non-zero index (one atomicMax per wavefront).
 struct FuseIn {
     const uint64_t* x1 = nullptr;
     const uint64_t* x2 = nullptr;
     uint32_t* bad = nullptr;
+    // MODE 3
+    const uint64_t* chat = nullptr;       // [instances][m], same tiling as the data
+    const uint64_t* untwist = nullptr;    // [m], Montgomery form
+    uint64_t half_m_inv = 0;              // (2m)^-1, Montgomery form
+    uint64_t* quotient = nullptr;         // [instances][m], natural order
+    uint32_t* top = nullptr;              // [instances]: 1 + highest non-zero index
 };
 template <class A, int LT, bool RAW_IN, bool RAW_OUT, int MODE = 0>
 __device__ __forceinline__ void tile_forward_body(uint64_t* __restrict__ data, size_t total, const ModParams& p,
@@ -212,7 +222,7 @@ __device__ __forceinline__ void tile_forward_body(uint64_t* __restrict__ data, s
         } else {
             static_assert(std::is_same_v<A, ArithGold> && !RAW_IN, "fused elementwise work: first pass of a Goldilocks transform");
             const rsrc_t r1 = make_rsrc(fuse.x1 + tile_base, tile_bytes);
-            if constexpr (MODE == 1) {
+            if constexpr (MODE == 1 || MODE == 3) {
                 uint64_t o1[kRegs];
 #pragma unroll
                 for (int k = 0; k < kRegs; ++k) o1[k] = buf_load64(r1, base * 8u, reg_offset<LO, R>(k) * 8u);
@@ -266,6 +276,61 @@ __device__ __forceinline__ void tile_forward_body(uint64_t* __restrict__ data, s
 
     // coalesced write-out: lane t stores tile indices t + 256 k
     const uint64_t* const col = lds + lds_slot(t);
+    if constexpr (MODE == 3) {
+        // The finish, in the coalesced mapping (the last round's own mapping holds 16 consecutive words per lane: c_hat and the
+        // untwist table would be read with a 128-byte lane stride, measured 100 us per 2^24 words).  Lane t takes z at tile indices
+        // p = t + 256 k (bit-reversed order), forms Q there, and a second trip through the tile puts Q at its natural index.
+        // Slot map of that trip: nat + (nat >> S), S = log m - 6 — a wavefront's 64 natural indices are 2^S apart (bit reversal
+        // of consecutive p), the pad spreads them over all banks; the coalesced read-back stays conflict-free.
+        constexpr int S = LT >= 10 ? LT - 6 : 4;
+        const rsrc_t chat = make_rsrc(fuse.chat + tile_base, tile_bytes);
+        const rsrc_t untw = make_rsrc(fuse.untwist, 8u << p.logn);
+        const rsrc_t out = make_rsrc(fuse.quotient + tile_base, tile_bytes);
+        uint64_t h[kRegs];
+        {
+            uint64_t c[kRegs], uw[kRegs];
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k) {
+                c[k] = buf_load64<kAuxStream>(chat, t * 8u, (uint32_t)k * kThreads * 8u);
+                uw[k] = buf_load64(untw, ((block_pos + t + (uint32_t)k * kThreads) & nmask) * 8u, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k)   // z is a lazy 64-bit representative (ArithGold::ct): gold_mul_mont takes any
+                h[k] = gold_sub(gold_mul_mont(A::load(c[k], p), fuse.half_m_inv), gold_mul_mont(col[lds_slot((uint32_t)k * kThreads)], uw[k]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k) {
+            const uint32_t at = t + (uint32_t)k * kThreads;
+            const uint32_t nat = (at & ~nmask) | (__brev(at & nmask) >> (32 - LT));       // LT = log m (single-pass transform)
+            lds[nat + (nat >> S)] = h[k];
+        }
+        __syncthreads();
+        constexpr int kGroup = LT >= 8 ? 1 << (LT - 8) : 1;     // registers per instance
+#pragma unroll
+        for (int g = 0; g < kRegs / kGroup; ++g) {
+            uint32_t best = 0;                                   // wave-uniform for log m >= 6
+#pragma unroll
+            for (int kk = 0; kk < kGroup; ++kk) {
+                const int k = g * kGroup + kk;
+                const uint32_t at = t + (uint32_t)k * kThreads;
+                const bool live = at * 8u < tile_bytes;
+                const uint64_t q = lds[at + (at >> S)];
+                buf_store64<kAuxStream>(out, t * 8u, (uint32_t)k * kThreads * 8u, q);
+                if constexpr (LT >= 6) {   // a wavefront's 64 consecutive words belong to one instance: one atomic per wavefront and instance
+                    const uint64_t nz = __ballot(live && q != 0);
+                    if (nz) best = ((at & ~63u) & nmask) + 64u - (uint32_t)__clzll(nz);
+                } else if (live && q != 0) {
+                    atomicMax(&fuse.top[(tile_base + at) >> p.logn], (at & nmask) + 1u);
+                }
+            }
+            if constexpr (LT >= 6) {
+                const uint32_t first = t + (uint32_t)(g * kGroup) * kThreads;
+                if (best && (t & 63u) == 0) atomicMax(&fuse.top[(tile_base + first) >> p.logn], best);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < kRegs; ++k) {
         const uint64_t bits = col[lds_slot((uint32_t)k * kThreads)];

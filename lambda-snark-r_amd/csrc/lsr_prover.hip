@@ -233,12 +233,15 @@ static void quotient_pass(LsrQuotientPlan& p, const uint64_t* d_a, const uint64_
         }
         launch_ntt(*p.ntt, work, 2 * count, true, s, nullptr, p.twist.ptr);              // A, B on the coset psi H
         if (fuse) {
-            launch_ntt_forward_fused(*p.ntt, work, count, s, nullptr, 1, work + per_vector, nullptr, nullptr);   // (a b) -> coefficients, r1cs.rs:495
+            // (a b) -> coefficients (r1cs.rs:495) and the finish below in one launch: the product rides in the transform's read-in, the
+            // subtraction of c, the untwist, the bit reversal and the degree bound in its write-out (lsr_ntt_kernels.hpp, MODE 3)
+            launch_ntt_forward_finish(*p.ntt, work, count, s, work + per_vector, work + 2 * per_vector, p.untwist.ptr, p.half_m_inv, d_q, top);
         } else {
             hipLaunchKernelGGL(product_kernel, dim3(blocks_for(per_vector)), dim3(kBlock), 0, s, work, work + per_vector, per_vector);   // r1cs.rs:495
             launch_ntt(*p.ntt, work, count, false, s);                                   // back to (twisted, bit-reversed) coefficients
         }
-        if (p.logm >= 12) {
+        if (fuse) {
+        } else if (p.logm >= 12) {
             hipLaunchKernelGGL(finish_quotient_kernel<true>, dim3(static_cast<unsigned>(per_vector / kSplitTile)), dim3(kBlock), 0, s, work,
                                work + 2 * per_vector, p.untwist.ptr, p.half_m_inv, d_q, top, p.logm, per_vector);
         } else {

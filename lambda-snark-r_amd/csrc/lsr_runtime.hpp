@@ -123,6 +123,8 @@ void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inve
 bool ntt_forward_can_fuse(const NttContext& ctx);
 void launch_ntt_forward_fused(const NttContext& ctx, uint64_t* d_data, size_t batch, hipStream_t stream, const uint64_t* src, int mode, const uint64_t* x1,
                               const uint64_t* x2, uint32_t* bad);
+void launch_ntt_forward_finish(const NttContext& ctx, const uint64_t* d_data, size_t batch, hipStream_t stream, const uint64_t* x1,
+                               const uint64_t* chat, const uint64_t* untwist, uint64_t half_m_inv, uint64_t* quotient, uint32_t* top);
 void launch_top_round_forward(const NttContext& ctx, uint64_t* d_dst, const uint64_t* d_src, size_t polys, hipStream_t stream);
 void launch_top_round_inverse(const NttContext& ctx, uint64_t* d_data, size_t polys, hipStream_t stream, const uint64_t* add);
 // the same round with the added residues sampled in the pass (CDT Gaussian per polynomial, lsr_sampler.hpp) instead of read

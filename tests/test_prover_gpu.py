@@ -275,6 +275,44 @@ def test_quotient_fused_elementwise_stages_agree(pkg, oracle, m, monkeypatch):
         assert lens[i] == ln and np.array_equal(out["1"][0][i], want)
 
 
+@pytest.mark.parametrize("m", [8, 64, 256, 1024, 4096])
+def test_quotient_degree_bound_of_every_instance_in_a_tile(pkg, oracle, m):
+    """The trimmed length comes from the write-out of the last transform (one atomic per wavefront and instance at m >= 64, per
+    word below): instances whose A, B have prescribed degrees d1 + d2 >= m give deg Q = d1 + d2 - m exactly (leading coefficients
+    non-zero, C = A B on the domain — r1cs.rs:505-511 trims trailing zeros), laid out so that every position of a 4096-word tile, a
+    tile boundary and a ragged last tile are hit; the highest non-zero index sits in every 64-word run in turn."""
+    import torch
+    batch = 2 * (4096 // m) + 3 if m < 4096 else 5
+    rng = np.random.default_rng(31 + m)
+    w = oracle.prover_omega(m)
+    a = np.zeros((batch, m), dtype=np.uint64); b = np.zeros_like(a); want_len = np.zeros(batch, dtype=np.uint32)
+    for i in range(batch):
+        deg_q = (i * 37 + 5 * (i // 3)) % (m - 1)                      # 0 .. m-2, spread over the runs
+        d1 = int(rng.integers(deg_q + 1, m))                            # d1 + d2 = m + deg_q, both below m
+        d2 = m + deg_q - d1
+        pa = np.zeros(m, dtype=np.uint64); pb = np.zeros(m, dtype=np.uint64)
+        pa[:d1 + 1] = rng.integers(1, Q, d1 + 1, dtype=np.uint64); pb[:d2 + 1] = rng.integers(1, Q, d2 + 1, dtype=np.uint64)
+        a[i], b[i] = oracle.cyclic_forward(pa, Q, w), oracle.cyclic_forward(pb, Q, w)
+        want_len[i] = deg_q + 1
+    c = np.array([[int(x) * int(y) % Q for x, y in zip(ra, rb)] for ra, rb in zip(a, b)], dtype=np.uint64)
+    plan = pkg.QuotientPlan(m, device=0)
+    quot, lens = plan.quotient_batch(a, b, c)
+    assert np.array_equal(lens, want_len)
+    for i in range(batch):
+        assert quot[i, lens[i] - 1] != 0 and not quot[i, lens[i]:].any()
+    for i in ([0, 1, batch // 2, batch - 1] if m <= 1024 else [0, batch - 1]):
+        want, ln = oracle.quotient(a[i], b[i], c[i])
+        assert ln == lens[i] and np.array_equal(quot[i], want)
+    # the device entry point, with stale lengths in the output array
+    da, db, dc = (torch.from_numpy(v.view(np.int64)).cuda() for v in (a, b, c))
+    dq = torch.full_like(da, -1)
+    dl = torch.full((batch,), -1, dtype=torch.int32, device="cuda")
+    plan.quotient_device(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, dq.data_ptr(), dl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dl.cpu().numpy().view(np.uint32), lens) and np.array_equal(dq.cpu().numpy().view(np.uint64), quot)
+    plan.close()
+
+
 # ---- compute_quotient_poly(witness) in full: sparse products + pipeline -------------------------------------------------
 def random_r1cs(rng, m, free_vars, fan_in=3):
     """m constraints (A_i.z)(B_i.z) = z[free_vars + i] over free_vars + m variables; A_i, B_i touch earlier variables only,

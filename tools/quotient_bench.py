@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 
 pkg = entry.load_package()
+if os.environ.get("LIBVARIANT"):          # an experiment build of the library (csrc/Makefile VARIANT=...), loaded explicitly
+    pkg._abi.use_library(os.path.join(os.path.dirname(pkg._abi.LIB_PATH), "liblambda_snark_core_%s.so" % os.environ["LIBVARIANT"]))
 m = int(os.environ.get("M", 4096)); batch = int(os.environ.get("B", 4096)); reps = int(os.environ.get("REPS", 10))
 plan = pkg.QuotientPlan(m, device=0)
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)
