@@ -157,13 +157,35 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU; the library has no CPU fallback")
+    # BENCH_REHEARSE_SHARED_GPU=1 (development): every rank of a torch.distributed.run launch uses device 0 and the job's barriers
+    # and reductions run over gloo — the N > 1 control flow of this file (matched collectives, the config-4 leg with waiting
+    # ranks, rank 0's line) on a one-GPU box.  The line then says so and its value is not a scaling figure.
+    rehearsal = os.environ.get("BENCH_REHEARSE_SHARED_GPU") == "1"
+    if rehearsal:
+        local = 0
+        os.environ["LAMBDA_SNARK_DEVICE"] = "0"
     torch.cuda.set_device(local)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run (any world size)
+    reduce_device = "cpu" if rehearsal else "cuda"
     cpu_group = None
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        if world > 1:    # a CPU-side group: ranks that only WAIT (config-4 leg) must not spin in a collective kernel on their GPU
-            cpu_group = dist.new_group(backend="gloo")
+        # gloo announces its connections on the process's stdout ("[Gloo] Rank 0 is connected to ..."): the job's stdout carries
+        # rank 0's JSON line and nothing else, so file descriptor 1 points at stderr while the groups are set up
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            if world > 1:    # a CPU-side group: ranks that only WAIT (config-4 leg) must not spin in a collective kernel on their GPU
+                cpu_group = dist.new_group(backend="gloo")
+                dist.barrier(group=cpu_group)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     pkg = entry.load_package()
     ctx = pkg.NttContext(Q16, N, device=local)
@@ -204,7 +226,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     verified = bool(torch.equal(polys[:8], reference_copy))        # fwd∘inv identity survived every step
@@ -285,7 +307,7 @@ def main():
         c_times = timed_commit_steps(csteps)
         c_el = float(np.sum(c_times))
         if use_dist:
-            t = torch.tensor([c_el], dtype=torch.float64, device="cuda")
+            t = torch.tensor([c_el], dtype=torch.float64, device=reduce_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             c_el = float(t.item())
         commit_bytes = 3 * k * N * 8      # read r + read e1 + write u (6 291 456 B at k = 4)
@@ -502,7 +524,7 @@ def main():
             "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64",                                 # residues mod q in uint64; the mechanism of the products is in extra.arith
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on device 0, gloo)" if rehearsal else ""),
             "config": {"workload": "config2: batched forward+inverse negacyclic NTT, n=2^16, 4096 polys/GPU, q=17592182243329 (44-bit)",
                        "polys_per_gpu": args.polys, "ring_degree": N, "modulus": Q16, "parallelism": f"independent batches x{world}, no collectives"},
             # achieved = ALGORITHMIC bytes (1 MiB per transform) / measured time of one forward batch launch sequence

@@ -197,3 +197,30 @@ def test_default_device_never_wraps_around(pkg, lib, monkeypatch):
     h = lib.lsr_ntt_context_create_on(12289, 256, 0)         # an explicit device ignores the environment
     assert h
     lib.ntt_context_free(h)
+
+
+def test_bench_with_two_ranks_prints_one_line(tmp_path):
+    """bench.py launched the way the driver launches it for N = 2 (torch.distributed.run, one process per rank), in the
+    rehearsal mode that maps both ranks onto device 0 and runs the job's barriers and reductions over gloo: the N > 1 control
+    flow — matched collectives in every section, the config-4 leg with a waiting rank, gloo's own chatter kept off stdout —
+    ends with exit code 0 and exactly ONE JSON line on stdout, from rank 0, counting both ranks' transforms."""
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BENCH_REHEARSE_SHARED_GPU="1")
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(name, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--polys", "256", "--commits", "64"]
+    done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, done.stdout[:2000]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and "REHEARSAL" in line["data"]
+    assert line["extra"]["verified_roundtrip"] and line["extra"]["commit_input_preserved"]
+    assert abs(line["value"] - 2 * 256 * 2 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    assert "cpu_baseline" not in line and line["extra"]["config4"].get("devices") == 1
