@@ -103,7 +103,9 @@ int lsr_lwe_commit_batch_flat_device(LweContext* ctx, const uint64_t* messages, 
  * strided transform rounds (three launches per chunk).  lsr_lwe_pipeline names the path a context takes: "tile", "fused",
  * "fused-matvec" (only the matrix-vector workload is fused), "general".
  * Calls on one context are ordered one behind the other (each waits for the previous call's last kernel), whatever streams the
- * caller passes; results are ready when `stream` has drained.  0 / -1. */
+ * caller passes; the synchronous entry points of the same context (lwe_commit, lwe_verify_opening, lwe_linear_combine, the batch
+ * and sharded calls) and lwe_context_free wait for a pending asynchronous call before they touch the context's workspaces.
+ * Results are ready when `stream` has drained.  0 / -1. */
 int lsr_lwe_commit_keys(const LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds,
                         uint64_t* out_keys) LSR_NOEXCEPT;
 int lsr_lwe_commit_rows_device(LweContext* ctx, const uint64_t* d_messages, size_t msg_len, size_t batch,

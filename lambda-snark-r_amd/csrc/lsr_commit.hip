@@ -268,6 +268,7 @@ static void destroy_lwe_context(LweContext* c) {
     if (!c) return;
     try {
         DeviceGuard guard(c->device);
+        if (c->ev_last) (void)hipEventSynchronize(c->ev_last);      // an asynchronous call still running on a caller's stream: let it finish first
         // zeroize the secret key and the scratch that held commitment randomness (commitment.h:34)
         volatile uint32_t* secret = c->keys.sec.w;
         for (int i = 0; i < 8; ++i) secret[i] = 0;
@@ -368,6 +369,11 @@ static void begin_async(const LweContext& c, hipStream_t s) {
 static void end_async(const LweContext& c, hipStream_t s) {
     if (!c.ev_last) LSR_HIP(hipEventCreateWithFlags(&c.ev_last, hipEventDisableTiming));
     LSR_HIP(hipEventRecord(c.ev_last, s));
+}
+// a SYNCHRONOUS entry point (its work runs on the context's own stream and is complete when it returns; caller holds c.mutex):
+// an asynchronous call enqueued earlier on a caller's stream may still be using the workspaces — wait for it first
+static void wait_for_async(const LweContext& c) {
+    if (c.ev_last) LSR_HIP(hipEventSynchronize(c.ev_last));
 }
 
 // MIXED schedule of the 4 + 12 pipeline (n = 2^16, blinding residues given; caller holds c.mutex): launch t carries the
@@ -742,19 +748,26 @@ static void commit_batch_flat_host(const LweContext& c, const uint64_t* messages
     const bool two = batch > chunk;
     if (c.ws_rows.count < slot * (two ? 2 : 1)) c.ws_rows.allocate(slot * (two ? 2 : 1));
     size_t index = 0;
-    for (size_t done = 0; done < batch; done += chunk, ++index) {
-        const size_t now = std::min(chunk, batch - done);
-        const int b = static_cast<int>(index & 1);
-        uint64_t* const rows = c.ws_rows.ptr + (two ? b * slot : 0);
-        if (index >= 2) LSR_HIP(hipEventSynchronize(c.ev_copied[b]));            // this buffer's previous rows have left
-        StagedInputs in;
-        stage_commit_inputs(c, messages + done * msg_len, msg_len, now, seeds ? seeds + done : nullptr, s, &in);
-        commit_rows_device(c, in.d_msgs, msg_len, now, in.d_keys, rows, s);
-        LSR_HIP(hipEventRecord(c.ev_chunk[b], s));
-        LSR_HIP(hipStreamWaitEvent(c.copy_stream, c.ev_chunk[b], 0));
-        LSR_HIP(hipMemcpyAsync(out_words + done * words, rows, now * words * 8, hipMemcpyDeviceToHost, c.copy_stream));
-        LSR_HIP(hipEventRecord(c.ev_copied[b], c.copy_stream));
-        LSR_HIP(hipStreamSynchronize(s));      // the staging areas of the inputs (pinned host block, key vector) are reused by the next chunk
+    try {
+        for (size_t done = 0; done < batch; done += chunk, ++index) {
+            const size_t now = std::min(chunk, batch - done);
+            const int b = static_cast<int>(index & 1);
+            uint64_t* const rows = c.ws_rows.ptr + (two ? b * slot : 0);
+            if (index >= 2) LSR_HIP(hipEventSynchronize(c.ev_copied[b]));            // this buffer's previous rows have left
+            StagedInputs in;
+            stage_commit_inputs(c, messages + done * msg_len, msg_len, now, seeds ? seeds + done : nullptr, s, &in);
+            commit_rows_device(c, in.d_msgs, msg_len, now, in.d_keys, rows, s);
+            LSR_HIP(hipEventRecord(c.ev_chunk[b], s));
+            LSR_HIP(hipStreamWaitEvent(c.copy_stream, c.ev_chunk[b], 0));
+            LSR_HIP(hipMemcpyAsync(out_words + done * words, rows, now * words * 8, hipMemcpyDeviceToHost, c.copy_stream));
+            LSR_HIP(hipEventRecord(c.ev_copied[b], c.copy_stream));
+            LSR_HIP(hipStreamSynchronize(s));      // the staging areas of the inputs (pinned host block, key vector) are reused by the next chunk
+        }
+    } catch (...) {
+        // the caller gets -1 and may free `out_words` at once: no copy of an earlier piece may still be writing into it
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(c.copy_stream);
+        throw;
     }
     LSR_HIP(hipStreamSynchronize(c.copy_stream));
 }
@@ -944,6 +957,7 @@ static int verify_opening(const LweContext& c, const LweCommitment* cm, const ui
     }
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
+    wait_for_async(c);
     // a single call is launch-bound: the row goes up in one copy as it is (cm->data IS the wire row) and the canonicity screening
     // happens on the device with everything else
     int result = -1;
@@ -974,6 +988,7 @@ static void verify_opening_batch(const LweContext& c, const LweCommitment* const
     if (live.empty()) return;
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
+    wait_for_async(c);
     hipStream_t s = work_stream(*c.ntt);
     const size_t chunk = verify_chunk(c, live.size());
     ensure_host_stage(c, chunk * (row + msg_len));
@@ -1020,6 +1035,7 @@ static void verify_opening_batch_flat(const LweContext& c, const uint64_t* words
     }
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
+    wait_for_async(c);
     verify_host_rows(c, words, messages, msg_len, count, results, work_stream(*c.ntt));
 }
 
@@ -1027,6 +1043,7 @@ static LweCommitment* linear_combine(const LweContext& c, const LweCommitment** 
     const size_t body_words = (size_t)(c.k + 1) * c.n;
     DeviceGuard guard(c.device);
     std::lock_guard<std::mutex> lock(c.mutex);
+    wait_for_async(c);
     hipStream_t s = work_stream(*c.ntt);
     // bodies are gathered `group` at a time (<= 64 MiB) in pinned memory, uploaded in one copy and folded in by one kernel
     const size_t group = std::max<size_t>(1, std::min<size_t>(count, (size_t(64) << 20) / (body_words * 8)));
@@ -1203,6 +1220,7 @@ int lwe_commit_batch(LweContext* ctx, const uint64_t* messages, size_t msg_len, 
     try {
         lsr::DeviceGuard guard(ctx->device);
         std::lock_guard<std::mutex> lock(ctx->mutex);
+        lsr::wait_for_async(*ctx);
         const size_t per_commit = (3 * (size_t)ctx->k + 3) * ctx->n * 8;
         const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, (1ull << 30) / per_commit));
         size_t done = 0;
@@ -1231,6 +1249,7 @@ static int commit_batch_flat(const char* where, LweContext* ctx, const uint64_t*
     try {
         lsr::DeviceGuard guard(ctx->device);
         std::lock_guard<std::mutex> lock(ctx->mutex);
+        lsr::wait_for_async(*ctx);
         const size_t words = lsr::kHeaderWords + ((size_t)ctx->k + 1) * ctx->n;
         const size_t per_commit = (4 * (size_t)ctx->k + 5) * ctx->n * 8;
         const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, (1ull << 30) / per_commit));
@@ -1467,6 +1486,7 @@ static int mlwe_matvec_batch_sharded(LweContext* const* ctxs, int shards, uint64
         if (!d_r[g] || !d_e1[g]) throw std::runtime_error("NULL device array for a non-empty shard");
         const LweContext& c = *ctxs[g];
         std::lock_guard<std::mutex> lock(c.mutex);
+        lsr::wait_for_async(c);
         lsr::DeviceBuffer<uint64_t> d_u(count * vec_words);
         hipStream_t s = lsr::work_stream(*c.ntt);
         lsr::ensure_copy_stream(c);

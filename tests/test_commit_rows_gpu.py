@@ -286,4 +286,22 @@ def test_asynchronous_calls_on_one_context_are_ordered(pkg):
         assert torch.equal(rows, want), it
         assert int(res.sum().item()) == batch, it
         assert torch.equal(d_u, d_u0), it
-    ctx.close()
+    # a SYNCHRONOUS entry point right behind an asynchronous call (no synchronisation in between): it waits for the pending work before
+    # it uses the shared workspaces — the legacy call's commitment is the oracle-checked row, and the rows of the pending call are intact
+    for it in range(5):
+        rows = torch.zeros((batch, words), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        assert ctx._lib.lsr_lwe_commit_rows_device(ctx.handle, d_msgs.data_ptr(), msg_len, batch, d_keys.data_ptr(), rows.data_ptr(), a.cuda_stream) == 0
+        one = pkg.Commitment(ctx, [int(x) for x in msgs[3]], int(seeds[3]))        # lwe_commit, no synchronisation before it
+        assert pkg.verify_opening_with_context(ctx, one, [int(x) for x in msgs[3]])
+        got = one.as_words()
+        torch.cuda.synchronize()
+        assert torch.equal(rows, want), it
+        assert np.array_equal(got.view(np.int64), want[3].cpu().numpy()), it
+    ctx.close()        # with nothing pending
+    ctx2 = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+    rows = torch.zeros((batch, words), dtype=torch.int64, device="cuda")
+    assert ctx2._lib.lsr_lwe_commit_rows_device(ctx2.handle, d_msgs.data_ptr(), msg_len, batch, d_keys.data_ptr(), rows.data_ptr(), a.cuda_stream) == 0
+    ctx2.close()       # lwe_context_free with an asynchronous call pending: it lets the call finish, then zeroizes
+    torch.cuda.synchronize()
+    assert torch.equal(rows, want)
