@@ -52,8 +52,9 @@ uint32_t lsr_quotient_plan_size(const LsrQuotientPlan* plan) LSR_NOEXCEPT;
 int lsr_quotient_batch(LsrQuotientPlan* plan, const uint64_t* a_evals, const uint64_t* b_evals, const uint64_t* c_evals,
                        size_t batch, uint64_t* quotient, uint32_t* quotient_len) LSR_NOEXCEPT;
 /* same on device-resident buffers, asynchronous on `stream`; d_quotient [batch][m], d_quotient_len [batch].  A plan owns one
- * workspace: calls on the same plan must be ordered (one stream, or events between streams); the first call of a given
- * batch size allocates, so make it outside a stream capture. */
+ * workspace: the library runs the calls on one plan one behind the other whatever streams they are given (a call waits on the
+ * host for the previous asynchronous call's last kernel before it enqueues — use one plan per stream for concurrency); the
+ * first call of a given batch size allocates, so make it outside a stream capture. */
 int lsr_quotient_batch_device(LsrQuotientPlan* plan, const uint64_t* d_a_evals, const uint64_t* d_b_evals,
                               const uint64_t* d_c_evals, size_t batch, uint64_t* d_quotient, uint32_t* d_quotient_len,
                               void* stream) LSR_NOEXCEPT;

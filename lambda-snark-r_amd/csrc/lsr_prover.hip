@@ -180,6 +180,7 @@ struct LsrQuotientPlan {
     lsr::DeviceBuffer<uint32_t> io_len;
     size_t chunk = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t ev_last = nullptr;             // end of the last asynchronous call: the next call on this plan (any stream) starts behind it
     // read from the environment ONCE, when the plan is created
     int chunk_log2 = 26;                      // LAMBDA_SNARK_QUOTIENT_CHUNK_LOG2: evaluations per pass and plane
     bool fuse = true;                         // LAMBDA_SNARK_QUOTIENT_FUSE=0: the a b = c test and the coset product as kernels of their own
@@ -259,6 +260,9 @@ static void quotient_device(LsrQuotientPlan& p, const uint64_t* d_a, const uint6
                             uint32_t* d_len, hipStream_t s) {
     DeviceGuard guard(p.device);
     std::lock_guard<std::mutex> lock(p.mutex);
+    // the workspace planes are the plan's: calls on one plan run one behind the other whatever streams the caller passes (and a
+    // workspace about to grow is not freed under a call that still uses it)
+    if (p.ev_last) LSR_HIP(hipEventSynchronize(p.ev_last));
     const size_t chunk = quotient_chunk(p, batch);
     ensure_workspace(p, chunk, false);
     for (size_t done = 0; done < batch; done += chunk) {
@@ -266,11 +270,14 @@ static void quotient_device(LsrQuotientPlan& p, const uint64_t* d_a, const uint6
         const size_t off = done << p.logm;
         quotient_pass(p, d_a + off, d_b + off, d_c + off, now, d_q + off, d_len + done, s);
     }
+    if (!p.ev_last) LSR_HIP(hipEventCreateWithFlags(&p.ev_last, hipEventDisableTiming));
+    LSR_HIP(hipEventRecord(p.ev_last, s));
 }
 
 static void quotient_host(LsrQuotientPlan& p, const uint64_t* a, const uint64_t* b, const uint64_t* c, size_t batch, uint64_t* q, uint32_t* len) {
     DeviceGuard guard(p.device);
     std::lock_guard<std::mutex> lock(p.mutex);
+    if (p.ev_last) LSR_HIP(hipEventSynchronize(p.ev_last));      // an asynchronous call still using the planes
     const size_t chunk = quotient_chunk(p, batch);
     ensure_workspace(p, chunk, true);
     for (size_t done = 0; done < batch; done += chunk) {
@@ -291,6 +298,10 @@ static void destroy_plan(LsrQuotientPlan* p) {
     if (!p) return;
     try {
         DeviceGuard guard(p->device);
+        if (p->ev_last) {
+            (void)hipEventSynchronize(p->ev_last);
+            (void)hipEventDestroy(p->ev_last);
+        }
         if (p->stream) (void)hipStreamDestroy(p->stream);
         p->work.release();
         p->flags.release();
@@ -449,6 +460,7 @@ static void prover_run(LsrR1csProver& r, const uint64_t* witnesses, size_t batch
     LsrQuotientPlan& p = *r.plan;
     DeviceGuard guard(p.device);
     std::lock_guard<std::mutex> lock(p.mutex);
+    if (p.ev_last) LSR_HIP(hipEventSynchronize(p.ev_last));      // an asynchronous lsr_quotient_batch_device call still using the planes
     const size_t chunk = quotient_chunk(p, batch);
     ensure_workspace(p, chunk, true);
     if (r.witness_chunk < p.chunk) {

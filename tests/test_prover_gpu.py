@@ -239,6 +239,38 @@ def test_quotient_device_api_and_chunking(pkg, oracle, monkeypatch):
     plan.close()
 
 
+def test_calls_on_one_plan_are_ordered_whatever_the_streams(pkg, oracle):
+    """One plan, one workspace: asynchronous calls given DIFFERENT streams with no synchronisation between them, a host-API call
+    right behind them and the plan freed with a call pending — every result equals that of the calls made one at a time."""
+    import torch
+    m, batch = 1024, 2048
+    rng = np.random.default_rng(5150)
+    sets = [instances(rng, m, batch, spoil=(i, batch - 1 - i)) for i in range(3)]
+    plan = pkg.QuotientPlan(m, device=0)
+    want = [plan.quotient_batch(a, b, c) for a, b, c in sets]
+    dev = [tuple(torch.from_numpy(v.view(np.int64)).cuda() for v in abc) for abc in sets]
+    streams = [torch.cuda.Stream() for _ in sets]
+    for it in range(5):
+        outs = [(torch.full((batch, m), -1, dtype=torch.int64, device="cuda"), torch.full((batch,), -1, dtype=torch.int32, device="cuda")) for _ in sets]
+        torch.cuda.synchronize()
+        for (da, db, dc), (dq, dl), st in zip(dev, outs, streams):
+            plan.quotient_device(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, dq.data_ptr(), dl.data_ptr(), st.cuda_stream)
+        hq, hl = plan.quotient_batch(*sets[0])                       # host entry point, nothing synchronised before it
+        torch.cuda.synchronize()
+        assert np.array_equal(hl, want[0][1]) and np.array_equal(hq[hl > 0], want[0][0][hl > 0])
+        for (dq, dl), (wq, wl) in zip(outs, want):
+            lens = dl.cpu().numpy().view(np.uint32)
+            assert np.array_equal(lens, wl), it
+            assert np.array_equal(dq.cpu().numpy().view(np.uint64)[lens > 0], wq[wl > 0]), it
+    dq = torch.full((batch, m), -1, dtype=torch.int64, device="cuda"); dl = torch.full((batch,), -1, dtype=torch.int32, device="cuda")
+    da, db, dc = dev[1]
+    plan.quotient_device(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, dq.data_ptr(), dl.data_ptr(), streams[1].cuda_stream)
+    plan.close()                                                      # lsr_quotient_plan_free with the call pending
+    torch.cuda.synchronize()
+    lens = dl.cpu().numpy().view(np.uint32)
+    assert np.array_equal(lens, want[1][1]) and np.array_equal(dq.cpu().numpy().view(np.uint64)[lens > 0], want[1][0][lens > 0])
+
+
 @pytest.mark.parametrize("m", [2, 64, 4096])
 def test_quotient_fused_elementwise_stages_agree(pkg, oracle, m, monkeypatch):
     """m <= 4096: the a b = c test rides in the read-in of C's interpolation and the coset product in the read-in of the last
