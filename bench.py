@@ -43,6 +43,14 @@ def parse():
     return ap.parse_args()
 
 
+def do_verify_long(fctx, lib, d_rows, d_msgs, msg_len, count, d_res, stream):
+    """every row opens to its message (lsr_lwe_verify_rows_device); outside any timed region"""
+    import torch
+    assert lib.lsr_lwe_verify_rows_device(fctx.handle, d_rows.data_ptr(), d_msgs.data_ptr(), msg_len, count, d_res.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    return bool((d_res == 1).all().item())
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -410,8 +418,32 @@ def main():
                 ok = all(np.array_equal(host_rows[i], orc.lwe_commit(fq, fn_, fk, 3.19, 0xC0DE + 3, [int(x) for x in fmsgs[j]], int(fseeds[j])))
                          for i, j in enumerate((0, fb - 1)))
                 full[label]["rows_match_cpu_oracle"] = bool(ok)
+            # FULL-LENGTH messages (msg_len = n: a polynomial's worth of field elements per commitment, what the Rust prover commits to),
+            # keys derived on the device from the device-resident messages (lsr_lwe_commit_keys_device): key schedule + commitments,
+            # nothing but the seeds from the host; beside it the host key derivation the device one replaces
+            if fn_ == 4096:
+                del d_msgs
+                long_msgs = torch.randint(0, int(fctx.plain_modulus), (fb, fn_), dtype=torch.int64, device="cuda", generator=gen)
+                d_keys2 = torch.empty_like(d_keys)
+                do_keys = lambda: lib.lsr_lwe_commit_keys_device(fctx.handle, long_msgs.data_ptr(), fn_, fb, fseeds.ctypes.data, d_keys2.data_ptr(), stream)
+                do_long = lambda: lib.lsr_lwe_commit_rows_device(fctx.handle, long_msgs.data_ptr(), fn_, fb, d_keys2.data_ptr(), d_rows.data_ptr(), stream)
+                do_both = lambda: (do_keys(), do_long())
+                assert do_keys() == 0 and do_long() == 0 and do_verify_long(fctx, lib, d_rows, long_msgs, fn_, fb, d_res, stream)
+                t_k = event_time(do_keys, max(3, reps // 2))
+                t_kc = event_time(do_both, max(3, reps // 2))
+                sample = long_msgs[:512].cpu().numpy().view(np.uint64)
+                t0 = time.perf_counter()
+                assert lib.lsr_lwe_commit_keys(fctx.handle, sample.ctypes.data, fn_, 512, fseeds.ctypes.data, fkeys.ctypes.data) == 0
+                t_host = time.perf_counter() - t0
+                full[label]["full_length_messages"] = {
+                    "msg_len": fn_, "commits_per_s_keys_and_rows_on_device": fb / t_kc, "device_key_derivation_per_s": fb / t_k,
+                    "host_key_derivation_per_s": 512 / t_host, "all_rows_open": True,
+                    "device_keys_equal_host_keys": bool(np.array_equal(d_keys2[:512].cpu().numpy().view(np.uint64), fkeys[:512]))}
+                del long_msgs, d_keys2
+            else:
+                del d_msgs
             fctx.close()
-            del d_rows, d_msgs, d_keys, d_res
+            del d_rows, d_keys, d_res
         extra["full_commit"] = full
 
     # ---- complete commitments at the reference's parameters (n = 4096, k = 2), PCIe included: host-visible throughput of the

@@ -105,9 +105,15 @@ int lsr_lwe_commit_batch_flat_device(LweContext* ctx, const uint64_t* messages, 
  * Calls on one context are ordered one behind the other (each waits for the previous call's last kernel), whatever streams the
  * caller passes; the synchronous entry points of the same context (lwe_commit, lwe_verify_opening, lwe_linear_combine, the batch
  * and sharded calls) and lwe_context_free wait for a pending asynchronous call before they touch the context's workspaces.
- * Results are ready when `stream` has drained.  0 / -1. */
+ * Results are ready when `stream` has drained.  0 / -1.
+ * lsr_lwe_commit_keys_device derives the same keys ON THE DEVICE from device-resident messages (seeds: a HOST array, every seed
+ * non-zero — seed 0 means fresh OS entropy, which only the host call can serve: -1), asynchronously on `stream`: the host
+ * derivation hashes every embedded message word (about 10 us per full-length message at n = 4096 on one core), which for long
+ * messages costs several times what the commitments themselves take on the GPU. */
 int lsr_lwe_commit_keys(const LweContext* ctx, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds,
                         uint64_t* out_keys) LSR_NOEXCEPT;
+int lsr_lwe_commit_keys_device(LweContext* ctx, const uint64_t* d_messages, size_t msg_len, size_t batch, const uint64_t* seeds,
+                               uint64_t* d_keys, void* stream) LSR_NOEXCEPT;
 int lsr_lwe_commit_rows_device(LweContext* ctx, const uint64_t* d_messages, size_t msg_len, size_t batch,
                                const uint64_t* d_keys, uint64_t* d_rows, void* stream) LSR_NOEXCEPT;
 /* `count` openings of device-resident rows against device-resident claimed messages (1 <= msg_len <= ring_degree):

@@ -192,6 +192,13 @@ class LweContext:
             raise CoreError("lsr_lwe_commit_keys failed: " + _abi.last_error())
         return keys
 
+    def commit_keys_device(self, d_messages, msg_len, seeds, d_keys, stream):
+        """``lsr_lwe_commit_keys_device``: the same keys derived on the device from device-resident messages (seeds: host array, all
+        non-zero), asynchronous on `stream`."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        if self._lib.lsr_lwe_commit_keys_device(self._h, d_messages, msg_len, seeds.size, seeds.ctypes.data, d_keys, stream) != 0:
+            raise CoreError("lsr_lwe_commit_keys_device failed: " + _abi.last_error())
+
     def commit_rows_device(self, d_messages, msg_len, batch, d_keys, d_rows, stream):
         """``lsr_lwe_commit_rows_device``: device pointers (ints) in, wire rows out, asynchronous on `stream`."""
         if self._lib.lsr_lwe_commit_rows_device(self._h, d_messages, msg_len, batch, d_keys, d_rows, stream) != 0:

@@ -125,6 +125,7 @@ SIGNATURES = {
     "lsr_fs_challenge_batch_device": (c_int, [vp, c_size, vp, c_size, c_size, u64, vp, vp, vp]),
     "lsr_lwe_commit_batch_flat_device": (c_int, [vp, vp, c_size, c_size, vp, vp]),
     "lsr_lwe_commit_keys": (c_int, [vp, vp, c_size, c_size, vp, vp]),
+    "lsr_lwe_commit_keys_device": (c_int, [vp, vp, c_size, c_size, vp, vp, vp]),
     "lsr_lwe_commit_rows_device": (c_int, [vp, vp, c_size, c_size, vp, vp, vp]),
     "lsr_lwe_verify_rows_device": (c_int, [vp, vp, vp, c_size, c_size, vp, vp]),
     "lsr_lwe_pipeline": (ctypes.c_char_p, [vp]),

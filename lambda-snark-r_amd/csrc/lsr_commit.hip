@@ -29,6 +29,7 @@
 #include "lsr_commit_fused.hpp"
 #include "lsr_commit_kernels.hpp"
 #include "lsr_commit_tile.hpp"
+#include "lsr_commit_keys.hpp"
 #include "lsr_keys.hpp"
 #include "lsr_runtime.hpp"
 #include "lsr_sampler.hpp"
@@ -96,6 +97,12 @@ struct LweContext {
     mutable uint64_t* host_in = nullptr;              // page-locked, kSmallInWords
     mutable lsr::DeviceBuffer<uint64_t> ws_in;        // its device twin: [keys 4 b | messages b x msg_len]
     mutable lsr::DeviceBuffer<uint64_t> ws_body;      // lwe_verify_opening: the body u || v of one commitment
+    // lsr_lwe_commit_keys_device: the seeds of a batch go up through a page-locked block of their own (the call is asynchronous:
+    // ev_seeds = that copy has been read, the block may be rewritten)
+    mutable uint64_t* host_seeds = nullptr;
+    mutable size_t host_seeds_words = 0;
+    mutable lsr::DeviceBuffer<uint64_t> ws_seeds;
+    mutable hipEvent_t ev_seeds = nullptr;
 };
 
 namespace lsr {
@@ -306,6 +313,14 @@ static void destroy_lwe_context(LweContext* c) {
         }
         if (c->ws_in.ptr) (void)hipMemset(c->ws_in.ptr, 0, c->ws_in.count * 8);
         c->ws_in.release();
+        if (c->host_seeds) {
+            volatile uint64_t* hs = c->host_seeds;
+            for (size_t i = 0; i < c->host_seeds_words; ++i) hs[i] = 0;
+            (void)hipHostFree(c->host_seeds);
+        }
+        if (c->ws_seeds.ptr) (void)hipMemset(c->ws_seeds.ptr, 0, c->ws_seeds.count * 8);
+        c->ws_seeds.release();
+        if (c->ev_seeds) (void)hipEventDestroy(c->ev_seeds);
         c->ws_body.release();
     } catch (...) {
     }
@@ -363,10 +378,12 @@ static void join_lanes(const LweContext& c, hipStream_t s, int lanes) {
 }
 
 // bracket of an asynchronous entry point (caller holds c.mutex): order this call behind the previous one on the same context
+// (a stream that records into a HIP graph: no bracket — lsr_runtime.hpp, stream_is_capturing)
 static void begin_async(const LweContext& c, hipStream_t s) {
-    if (c.ev_last) LSR_HIP(hipStreamWaitEvent(s, c.ev_last, 0));
+    if (c.ev_last && !stream_is_capturing(s)) LSR_HIP(hipStreamWaitEvent(s, c.ev_last, 0));
 }
 static void end_async(const LweContext& c, hipStream_t s) {
+    if (stream_is_capturing(s)) return;
     if (!c.ev_last) LSR_HIP(hipEventCreateWithFlags(&c.ev_last, hipEventDisableTiming));
     LSR_HIP(hipEventRecord(c.ev_last, s));
 }
@@ -579,13 +596,31 @@ struct StagedInputs {
     const uint64_t* d_msgs = nullptr;
     DeviceBuffer<uint64_t> big_msgs;       // a message batch larger than the context's scratch: dies with this object (after a sync)
 };
+// the device form of derive_commit_keys (lsr_commit_keys.hpp): d_seeds[batch] all non-zero, d_msgs[batch][msg_len] -> d_keys[batch][4]
+static void launch_commit_keys(const LweContext& c, const uint64_t* d_msgs, size_t msg_len, size_t batch, const uint64_t* d_seeds, uint64_t* d_keys,
+                               hipStream_t s) {
+    CommitKeysJob job{};
+    job.keys = d_keys;
+    job.msgs = d_msgs;
+    job.seeds = d_seeds;
+    job.msg_len = msg_len;
+    job.copy = static_cast<uint32_t>(std::min<size_t>(msg_len, c.n));
+    for (int i = 0; i < 4; ++i) job.id[i] = c.keys.id[i];
+    job.t = c.t;
+    hipLaunchKernelGGL(commit_keys_kernel, dim3(static_cast<unsigned>(batch)), dim3(kKeyThreads), 0, s, job);
+    LSR_HIP(hipGetLastError());
+}
+
 static void stage_commit_inputs(const LweContext& c, const uint64_t* messages, size_t msg_len, size_t batch, const uint64_t* seeds, hipStream_t s,
                                 StagedInputs* in) {
     ensure_input_space(c, batch);
     std::vector<uint64_t>& key_host = c.ws_key_host;
     key_host.resize(batch * 4);
     const size_t copy = std::min<size_t>(msg_len, c.n);
-    derive_commit_keys(c, messages, msg_len, batch, seeds, key_host.data());
+    // long messages: the keys are derived on the device from the uploaded messages (the host derivation hashes every embedded word —
+    // about 10 us per full-length message and core, more than the commitment costs the GPU); seed 0 = fresh OS entropy stays here
+    const bool device_keys = seeds && batch * copy >= (size_t(1) << 16) && std::all_of(seeds, seeds + batch, [](uint64_t v) { return v != 0; });
+    if (!device_keys) derive_commit_keys(c, messages, msg_len, batch, seeds, key_host.data());
     const size_t in_words = batch * 4 + (copy ? batch * msg_len : 0);
     if (in_words <= LweContext::kSmallInWords) {
         // one upload from page-locked memory instead of two staged ones (every caller synchronises the stream before it returns, so
@@ -601,13 +636,19 @@ static void stage_commit_inputs(const LweContext& c, const uint64_t* messages, s
         in->d_msgs = c.ws_in.ptr + batch * 4;
         return;
     }
-    LSR_HIP(hipMemcpyAsync(c.ws_keys.ptr, key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
+    if (device_keys) {   // (every caller synchronises `s` before it returns: the caller's seed array is read by then)
+        if (c.ws_seeds.count < batch) c.ws_seeds.allocate(std::max<size_t>(batch, 4096));
+        LSR_HIP(hipMemcpyAsync(c.ws_seeds.ptr, seeds, batch * 8, hipMemcpyHostToDevice, s));
+    } else {
+        LSR_HIP(hipMemcpyAsync(c.ws_keys.ptr, key_host.data(), batch * 32, hipMemcpyHostToDevice, s));
+    }
     uint64_t* d_msgs = c.ws_dm.ptr;
     if (batch * msg_len > c.ws_dm.count) {
         in->big_msgs.allocate(batch * msg_len);
         d_msgs = in->big_msgs.ptr;
     }
     if (copy) LSR_HIP(hipMemcpyAsync(d_msgs, messages, batch * msg_len * 8, hipMemcpyHostToDevice, s));
+    if (device_keys) launch_commit_keys(c, d_msgs, msg_len, batch, c.ws_seeds.ptr, c.ws_keys.ptr, s);
     in->d_keys = c.ws_keys.ptr;
     in->d_msgs = d_msgs;
 }
@@ -866,7 +907,7 @@ static void verify_rows_device(const LweContext& c, const uint64_t* d_rows, cons
     const size_t state_words = count + (count + 1) / 2;
     if (c.ws_vflags.count < state_words) c.ws_vflags.allocate(state_words);
     c.ws_vbad = reinterpret_cast<uint32_t*>(c.ws_vflags.ptr + count);
-    LSR_HIP(hipMemsetAsync(c.ws_vflags.ptr, 0, state_words * sizeof(unsigned long long), s));
+    zero_words_async(reinterpret_cast<uint64_t*>(c.ws_vflags.ptr), state_words, s);
     if (c.s_perm.ptr && c.logn == 12) {     // one launch, one workgroup per opening: the row is read once (lsr_commit_tile.hpp)
         const VerifyTileJob job{d_rows, d_msgs, (uint64_t)msg_len, c.ws_vflags.ptr, c.ws_vbad, (uint32_t)count, c.q, c.t};
         switch (k) {
@@ -1295,6 +1336,57 @@ int lsr_lwe_commit_keys(const LweContext* ctx, const uint64_t* messages, size_t 
         return 0;
     } catch (const std::exception& e) {
         lsr::set_last_error(std::string("lsr_lwe_commit_keys: ") + e.what());
+        return -1;
+    } catch (...) {
+        return -1;
+    }
+}
+
+// the same keys for device-resident messages, derived on the device (lsr_commit_keys.hpp); asynchronous on `stream`
+int lsr_lwe_commit_keys_device(LweContext* ctx, const uint64_t* d_messages, size_t msg_len, size_t batch, const uint64_t* seeds, uint64_t* d_keys,
+                               void* stream) noexcept {
+    if (!ctx || !seeds || !d_keys || (!d_messages && msg_len)) return -1;
+    if (batch == 0) return 0;
+    for (size_t j = 0; j < batch; ++j)
+        if (seeds[j] == 0) {
+            lsr::set_last_error("lsr_lwe_commit_keys_device: seed 0 asks for fresh OS entropy (commitment.h:52), which lives on the host — use lsr_lwe_commit_keys");
+            return -1;
+        }
+    if (batch > 0x7fffffffull) {
+        lsr::set_last_error("lsr_lwe_commit_keys_device: batch exceeds one launch (2^31 - 1 commitments)");
+        return -1;
+    }
+    try {
+        lsr::DeviceGuard guard(ctx->device);
+        std::lock_guard<std::mutex> lock(ctx->mutex);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (lsr::stream_is_capturing(s)) {     // the seeds travel through a host block that a replay would read again, with other seeds in it
+            lsr::set_last_error("lsr_lwe_commit_keys_device: not capturable into a HIP graph (host seeds)");
+            return -1;
+        }
+        lsr::begin_async(*ctx, s);
+        if (ctx->ev_seeds) LSR_HIP(hipEventSynchronize(ctx->ev_seeds));       // the previous call's upload has left the page-locked block
+        if (ctx->host_seeds_words < batch) {
+            if (ctx->host_seeds) {
+                std::memset(ctx->host_seeds, 0, ctx->host_seeds_words * 8);
+                LSR_HIP(hipHostFree(ctx->host_seeds));
+                ctx->host_seeds = nullptr;
+                ctx->host_seeds_words = 0;
+            }
+            const size_t words = std::max<size_t>(batch, 4096);
+            LSR_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->host_seeds), words * 8, hipHostMallocPortable));
+            ctx->host_seeds_words = words;
+        }
+        if (ctx->ws_seeds.count < batch) ctx->ws_seeds.allocate(std::max<size_t>(batch, 4096));
+        std::memcpy(ctx->host_seeds, seeds, batch * 8);
+        LSR_HIP(hipMemcpyAsync(ctx->ws_seeds.ptr, ctx->host_seeds, batch * 8, hipMemcpyHostToDevice, s));
+        if (!ctx->ev_seeds) LSR_HIP(hipEventCreateWithFlags(&ctx->ev_seeds, hipEventDisableTiming));
+        LSR_HIP(hipEventRecord(ctx->ev_seeds, s));
+        lsr::launch_commit_keys(*ctx, d_messages, msg_len, batch, ctx->ws_seeds.ptr, d_keys, s);
+        lsr::end_async(*ctx, s);
+        return 0;
+    } catch (const std::exception& e) {
+        lsr::set_last_error(std::string("lsr_lwe_commit_keys_device: ") + e.what());
         return -1;
     } catch (...) {
         return -1;

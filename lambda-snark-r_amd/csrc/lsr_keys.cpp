@@ -17,10 +17,8 @@ inline void quarter(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
     a += b; d ^= a; d = rotl(d, 8);
     c += d; b ^= c; b = rotl(b, 7);
 }
-constexpr uint32_t tag(char a, char b, char c, char d) {
-    return (uint32_t)(unsigned char)a | ((uint32_t)(unsigned char)b << 8) | ((uint32_t)(unsigned char)c << 16) | ((uint32_t)(unsigned char)d << 24);
-}
-constexpr uint64_t kP61 = (1ull << 61) - 1;
+constexpr uint32_t tag(char a, char b, char c, char d) { return key_tag(a, b, c, d); }
+constexpr uint64_t kP61 = kHashPrime61;
 inline uint64_t mul61(uint64_t a, uint64_t b) {   // a, b < 2^61 - 1
     const unsigned __int128 w = (unsigned __int128)a * b;
     uint64_t r = (uint64_t)(w & kP61) + (uint64_t)(w >> 61);
@@ -98,8 +96,8 @@ ContextKeys derive_context_keys(uint64_t key_seed) {
 }
 
 StreamKey derive_commit_key(uint64_t seed, const uint32_t id[4], const uint64_t* message, size_t copy, uint64_t t) {
-    const StreamKey base{{(uint32_t)seed, (uint32_t)(seed >> 32), tag('L', 'S', 'R', '2'), tag('C', 'M', 'I', 'T'), id[0], id[1], id[2], id[3]}};
-    const StreamKey points = kdf(base, tag('H', 'P', 'N', 'T'), 0, 0, 0);
+    const StreamKey base{{(uint32_t)seed, (uint32_t)(seed >> 32), kTagLsr2, kTagCommit, id[0], id[1], id[2], id[3]}};
+    const StreamKey points = kdf(base, kTagHashPoints, 0, 0, 0);
     const uint64_t x1 = point61(points.w[0], points.w[1]), x2 = point61(points.w[2], points.w[3]);
     uint64_t h1 = 0, h2 = 0, p1 = x1, p2 = x2;
     for (size_t i = 0; i < copy; ++i) {
@@ -109,8 +107,8 @@ StreamKey derive_commit_key(uint64_t seed, const uint32_t id[4], const uint64_t*
         p1 = mul61(p1, x1);
         p2 = mul61(p2, x2);
     }
-    const StreamKey step = kdf(base, tag('C', 'K', 'Y', '1'), (uint32_t)h1, (uint32_t)(h1 >> 32), 0);
-    return kdf(step, tag('C', 'K', 'Y', '2'), (uint32_t)h2, (uint32_t)(h2 >> 32), 0);
+    const StreamKey step = kdf(base, kTagCommitKey1, (uint32_t)h1, (uint32_t)(h1 >> 32), 0);
+    return kdf(step, kTagCommitKey2, (uint32_t)h2, (uint32_t)(h2 >> 32), 0);
 }
 
 }  // namespace lsr

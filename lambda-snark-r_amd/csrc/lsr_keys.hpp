@@ -23,6 +23,14 @@ struct StreamKey {
     uint32_t w[8];
 };
 
+// four-character labels of the key schedule, little endian (shared with the device derivation, lsr_commit_keys.hpp)
+constexpr uint32_t key_tag(char a, char b, char c, char d) {
+    return (uint32_t)(unsigned char)a | ((uint32_t)(unsigned char)b << 8) | ((uint32_t)(unsigned char)c << 16) | ((uint32_t)(unsigned char)d << 24);
+}
+constexpr uint32_t kTagLsr2 = key_tag('L', 'S', 'R', '2'), kTagCommit = key_tag('C', 'M', 'I', 'T'), kTagHashPoints = key_tag('H', 'P', 'N', 'T'),
+                   kTagCommitKey1 = key_tag('C', 'K', 'Y', '1'), kTagCommitKey2 = key_tag('C', 'K', 'Y', '2');
+constexpr uint64_t kHashPrime61 = (1ull << 61) - 1;
+
 // the key as the four little-endian 64-bit words the device kernels read
 inline void key_words(const StreamKey& k, uint64_t out[4]) {
     for (int i = 0; i < 4; ++i) out[i] = (uint64_t)k.w[2 * i] | ((uint64_t)k.w[2 * i + 1] << 32);

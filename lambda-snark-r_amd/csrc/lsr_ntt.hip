@@ -50,6 +50,26 @@ int default_device() {
     return 0;
 }
 
+bool stream_is_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &status) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return status != hipStreamCaptureStatusNone;
+}
+
+__global__ void __launch_bounds__(256) zero_words_kernel(uint64_t* __restrict__ dst, size_t words) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) dst[i] = 0;
+}
+void zero_words_async(uint64_t* dst, size_t words, hipStream_t stream) {
+    if (!words) return;
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>((words + 255) / 256, 4096));
+    hipLaunchKernelGGL(zero_words_kernel, dim3(grid), dim3(256), 0, stream, dst, words);
+    LSR_HIP(hipGetLastError());
+}
+
 DeviceGuard::DeviceGuard(int device) {
     if (hipGetDevice(&previous_) != hipSuccess) previous_ = -1;
     if (previous_ != device) {

@@ -216,7 +216,7 @@ static void quotient_pass(LsrQuotientPlan& p, const uint64_t* d_a, const uint64_
     uint64_t* work = p.work.ptr;
     uint32_t* top = p.flags.ptr;
     uint32_t* bad = p.flags.ptr + count;
-    LSR_HIP(hipMemsetAsync(p.flags.ptr, 0, 2 * count * sizeof(uint32_t), s));
+    zero_words_async(reinterpret_cast<uint64_t*>(p.flags.ptr), count, s);                 // top[count], bad[count]: 2 count u32 = count words
     // m <= 4096 (one tile launch per transform): the two elementwise kernels ride in the read-in of a transform — the a b = c test in
     // C's interpolation, the coset product in the last transform (the transforms are integer-VALU-bound, the extra loads cost nothing
     // and two passes over the planes disappear: profiles/r02b_quotient_fusion.txt).  A plan created under LAMBDA_SNARK_QUOTIENT_FUSE=0 keeps them apart.
@@ -250,7 +250,7 @@ static void quotient_pass(LsrQuotientPlan& p, const uint64_t* d_a, const uint64_
                                work, work + 2 * per_vector, p.untwist.ptr, p.half_m_inv, d_q, top, p.logm, per_vector);
         }
     } else {
-        LSR_HIP(hipMemsetAsync(d_q, 0, per_vector * 8, s));                              // m = 1: constants, Q = 0 when a b = c
+        zero_words_async(d_q, per_vector, s);                                            // m = 1: constants, Q = 0 when a b = c
     }
     hipLaunchKernelGGL(quotient_len_kernel, dim3(blocks_for(count, ~0u)), dim3(kBlock), 0, s, d_len, top, bad, count);
     LSR_HIP(hipGetLastError());
@@ -262,7 +262,9 @@ static void quotient_device(LsrQuotientPlan& p, const uint64_t* d_a, const uint6
     std::lock_guard<std::mutex> lock(p.mutex);
     // the workspace planes are the plan's: calls on one plan run one behind the other whatever streams the caller passes (and a
     // workspace about to grow is not freed under a call that still uses it)
-    if (p.ev_last) LSR_HIP(hipEventSynchronize(p.ev_last));
+    // (not while `s` records into a HIP graph: a captured sequence is ordered by the capture, lsr_runtime.hpp stream_is_capturing)
+    const bool capturing = stream_is_capturing(s);
+    if (p.ev_last && !capturing) LSR_HIP(hipEventSynchronize(p.ev_last));
     const size_t chunk = quotient_chunk(p, batch);
     ensure_workspace(p, chunk, false);
     for (size_t done = 0; done < batch; done += chunk) {
@@ -270,6 +272,7 @@ static void quotient_device(LsrQuotientPlan& p, const uint64_t* d_a, const uint6
         const size_t off = done << p.logm;
         quotient_pass(p, d_a + off, d_b + off, d_c + off, now, d_q + off, d_len + done, s);
     }
+    if (capturing) return;
     if (!p.ev_last) LSR_HIP(hipEventCreateWithFlags(&p.ev_last, hipEventDisableTiming));
     LSR_HIP(hipEventRecord(p.ev_last, s));
 }

@@ -123,6 +123,13 @@ void launch_ntt(const NttContext& ctx, uint64_t* d_data, size_t batch, bool inve
 bool ntt_forward_can_fuse(const NttContext& ctx);
 void launch_ntt_forward_fused(const NttContext& ctx, uint64_t* d_data, size_t batch, hipStream_t stream, const uint64_t* src, int mode, const uint64_t* x1,
                               const uint64_t* x2, uint32_t* bad);
+// true while `stream` records into a HIP graph: events recorded there belong to the capture (they cannot be waited for on the
+// host), so the per-object ordering brackets stand aside — a captured call sequence is ordered by the capture itself, and the
+// caller orders graph launches against other work on the same object
+bool stream_is_capturing(hipStream_t stream);
+// `words` 64-bit words at `dst` set to zero by a KERNEL on `stream` (device-API paths that may be captured into a HIP graph: a
+// captured hipMemsetAsync cleared the verdict state on the first replay only — tools/graph_probe.py, profiles/README.md)
+void zero_words_async(uint64_t* dst, size_t words, hipStream_t stream);
 void launch_ntt_forward_finish(const NttContext& ctx, const uint64_t* d_data, size_t batch, hipStream_t stream, const uint64_t* x1,
                                const uint64_t* chat, const uint64_t* untwist, uint64_t half_m_inv, uint64_t* quotient, uint32_t* top);
 void launch_top_round_forward(const NttContext& ctx, uint64_t* d_dst, const uint64_t* d_src, size_t polys, hipStream_t stream);

@@ -154,6 +154,7 @@ static void test_commitment(void) {
         CHECK(memcmp(keys, keys2, sizeof keys) == 0);           /* seed != 0: deterministic in (seed, context, message) */
         seeds[0] = 0;
         CHECK(lsr_lwe_commit_keys(ctx, msgs, ML, B, seeds, keys2) == 0 && memcmp(keys, keys2, 32) != 0);   /* seed == 0: fresh entropy */
+        CHECK(lsr_lwe_commit_keys_device(ctx, NULL, 0, B, seeds, (uint64_t*)keys2, NULL) == -1);           /* ... which the device variant refuses */
         free(rows);
     }
     lwe_context_free(ctx);

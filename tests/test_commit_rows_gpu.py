@@ -305,3 +305,95 @@ def test_asynchronous_calls_on_one_context_are_ordered(pkg):
     ctx2.close()       # lwe_context_free with an asynchronous call pending: it lets the call finish, then zeroizes
     torch.cuda.synchronize()
     assert torch.equal(rows, want)
+
+
+@pytest.mark.parametrize("n,k,msg_len", [(4096, 2, 0), (4096, 2, 1), (4096, 2, 5), (4096, 2, 255), (4096, 2, 256), (4096, 2, 257), (4096, 2, 1000),
+                                         (4096, 2, 4096), (4096, 2, 5000), (1024, 1, 1024), (65536, 4, 3000)])
+def test_device_key_derivation_equals_the_host_one(pkg, oracle, n, k, msg_len):
+    """lsr_lwe_commit_keys_device = lsr_lwe_commit_keys word for word (the keys ARE the commitment's randomness, so a single differing
+    bit changes every row): message lengths around the 256-lane stride of the hash, full length, beyond the ring degree (only the
+    first n words are embedded, commitment.cpp:146-149), message words >= t up to 2^64 - 1; then the rows made from the device's
+    keys against the CPU oracle's lwe_commit."""
+    import torch
+    q = 17592169062401 if n <= 4096 else 17592182243329
+    batch = 37 if msg_len <= 1000 else 9
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+    rng = np.random.default_rng(1000 + msg_len + n)
+    msgs = rng.integers(0, 2**64, size=(batch, msg_len), dtype=np.uint64)
+    if msg_len:
+        msgs[0] = rng.integers(0, ctx.plain_modulus, size=msg_len, dtype=np.uint64)
+        msgs[1, 0] = np.uint64(2**64 - 1); msgs[1, -1] = np.uint64(ctx.plain_modulus); msgs[2] = 0
+    seeds = rng.integers(1, 2**64, size=batch, dtype=np.uint64)
+    seeds[3] = seeds[4]                                                      # a reused seed: the message still separates the keys
+    want = ctx.commit_keys(msgs, seeds)
+    d_msgs = torch.from_numpy(msgs.view(np.int64)).cuda() if msg_len else None
+    d_keys = torch.full((batch, 4), -1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.commit_keys_device(d_msgs.data_ptr() if msg_len else None, msg_len, seeds, d_keys.data_ptr(), s)
+    torch.cuda.synchronize()
+    got = d_keys.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+    if msg_len:
+        assert not np.array_equal(got[3], got[4])
+    # rows from the device's keys (nothing but the seeds came from the host), against the oracle
+    words = ctx.commitment_words
+    d_rows = torch.zeros((batch, words), dtype=torch.int64, device="cuda")
+    ctx.commit_rows_device(d_msgs.data_ptr() if msg_len else None, msg_len, batch, d_keys.data_ptr(), d_rows.data_ptr(), s)
+    torch.cuda.synchronize()
+    rows = d_rows.cpu().numpy().view(np.uint64)
+    for j in ([0, 1, batch - 1] if n <= 4096 else [1]):
+        assert np.array_equal(rows[j], oracle.lwe_commit(q, n, k, SIGMA, KEY, [int(x) for x in msgs[j]], int(seeds[j]))), (msg_len, j)
+    ctx.close()
+
+
+def test_device_key_derivation_refuses_seed_zero_and_reuses_its_staging(pkg):
+    import torch
+    n, k, msg_len, batch = 4096, 2, 300, 5000
+    ctx = pkg.LweContext(pkg.Params(q=17592169062401, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+    rng = np.random.default_rng(77)
+    msgs = rng.integers(0, ctx.plain_modulus, size=(batch, msg_len), dtype=np.uint64)
+    d_msgs = torch.from_numpy(msgs.view(np.int64)).cuda()
+    seeds = rng.integers(1, 2**64, size=batch, dtype=np.uint64)
+    bad = seeds.copy(); bad[batch // 2] = 0
+    d_keys = torch.zeros((batch, 4), dtype=torch.int64, device="cuda")
+    with pytest.raises(pkg.CoreError, match="seed 0"):
+        ctx.commit_keys_device(d_msgs.data_ptr(), msg_len, bad, d_keys.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    # three calls in a row on three streams, nothing synchronised in between: every call uploads its seeds through the same page-locked
+    # block, which is rewritten only after the previous upload has been read
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    seed_sets = [seeds, seeds[::-1].copy(), np.roll(seeds, 17)]
+    outs = [torch.zeros((batch, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    for sd, out, st in zip(seed_sets, outs, streams):
+        ctx.commit_keys_device(d_msgs.data_ptr(), msg_len, sd, out.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    for sd, out in zip(seed_sets, outs):
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), ctx.commit_keys(msgs, sd))
+    ctx.close()
+
+
+def test_long_message_batches_derive_their_keys_on_the_device(pkg, oracle):
+    """The host entry points hand batches of long messages (>= 2^16 embedded words in all) to the device key derivation after the
+    upload; single commitments and short batches keep the host derivation.  Both must give the same commitment: the flat batch
+    against one-by-one lwe_commit calls and the oracle, and a batch with one seed 0 (fresh entropy: host derivation for the whole
+    batch) still opens."""
+    n, k, batch = 4096, 2, 24
+    q = 17592169062401
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+    rng = np.random.default_rng(99)
+    msgs = rng.integers(0, ctx.plain_modulus, size=(batch, n), dtype=np.uint64)
+    seeds = rng.integers(1, 2**64, size=batch, dtype=np.uint64)
+    rows = pkg.Commitment.batch_words(ctx, msgs, seeds)                      # 24 x 4096 words: device derivation
+    for j in (0, 11, batch - 1):
+        single = pkg.Commitment(ctx, [int(x) for x in msgs[j]], int(seeds[j]))   # host derivation
+        assert np.array_equal(single.as_words(), rows[j]), j
+    assert np.array_equal(rows[5], oracle.lwe_commit(q, n, k, SIGMA, KEY, [int(x) for x in msgs[5]], int(seeds[5])))
+    listed = pkg.Commitment.batch(ctx, msgs, seeds)                          # lwe_commit_batch: the same staging
+    assert all(np.array_equal(c.as_words(), rows[j]) for j, c in enumerate(listed))
+    assert pkg.verify_openings_words(ctx, rows, msgs) == [1] * batch
+    seeds0 = seeds.copy(); seeds0[7] = 0
+    rows0 = pkg.Commitment.batch_words(ctx, msgs, seeds0)
+    assert pkg.verify_openings_words(ctx, rows0, msgs) == [1] * batch
+    keep = np.arange(batch) != 7
+    assert np.array_equal(rows0[keep], rows[keep]) and not np.array_equal(rows0[7], rows[7])
+    ctx.close()

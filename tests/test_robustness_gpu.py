@@ -201,7 +201,56 @@ def test_quotient_device_api_is_graph_capturable(pkg, oracle):
             w, ln = oracle.quotient(a[i], b[i], c[i])
             assert lens[i] == ln and (ln == 0 or np.array_equal(quot[i], w))
         assert lens[3] == 0
+    # calls outside the capture afterwards: the plan's ordering event was never recorded into the graph, so the host entry point
+    # (which waits for it) and a plain asynchronous call both still work
+    hq, hl = plan.quotient_batch(a, b, c)
+    assert np.array_equal(hl, lens) and np.array_equal(hq[hl > 0], quot[hl > 0])
+    dq.zero_(); dl.zero_()
+    plan.quotient_device(da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, dq.data_ptr(), dl.data_ptr(), side.cuda_stream)
+    side.synchronize()
+    assert np.array_equal(dl.cpu().numpy().view(np.uint32), lens)
     plan.close()
+
+
+def test_commit_rows_are_graph_capturable_and_leave_the_context_usable(pkg, oracle):
+    """lsr_lwe_commit_rows_device + lsr_lwe_verify_rows_device of the tile pipeline captured into a HIP graph (one launch each, no
+    allocation after the warm-up), replayed, and then the synchronous lwe_commit / lwe_verify_opening on the same context: they wait
+    for the context's last-use event, which must not have been recorded into the capture."""
+    import torch
+    q, n, k, batch, msg_len = 17592169062401, 4096, 2, 12, 9
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0x5EED)
+    rng = np.random.default_rng(8)
+    msgs = rng.integers(0, ctx.plain_modulus, size=(batch, msg_len), dtype=np.uint64)
+    seeds = rng.integers(1, 2**63, size=batch, dtype=np.uint64)
+    keys = ctx.commit_keys(msgs, seeds)
+    d_msgs = torch.from_numpy(msgs.view(np.int64)).cuda(); d_keys = torch.from_numpy(keys.view(np.int64)).cuda()
+    rows = torch.zeros((batch, ctx.commitment_words), dtype=torch.int64, device="cuda")
+    res = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    both = lambda st: (ctx.commit_rows_device(d_msgs.data_ptr(), msg_len, batch, d_keys.data_ptr(), rows.data_ptr(), st),
+                       ctx.verify_rows_device(rows.data_ptr(), d_msgs.data_ptr(), msg_len, batch, res.data_ptr(), st))
+    with torch.cuda.stream(side):
+        both(side.cuda_stream)                                   # warm-up: workspaces
+    side.synchronize()
+    want = rows.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        both(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        rows.zero_(); res.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(rows, want) and int(res.sum().item()) == batch
+    one = pkg.Commitment(ctx, [int(x) for x in msgs[2]], int(seeds[2]))
+    assert np.array_equal(one.as_words().view(np.int64), want[2].cpu().numpy())
+    assert pkg.verify_opening_with_context(ctx, one, [int(x) for x in msgs[2]])
+    assert np.array_equal(one.as_words(), oracle.lwe_commit(q, n, k, 3.19, 0x5EED, [int(x) for x in msgs[2]], int(seeds[2])))
+    with pytest.raises(pkg.CoreError, match="not capturable"):
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=side):
+            ctx.commit_keys_device(d_msgs.data_ptr(), msg_len, seeds, d_keys.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    ctx.close()
 
 
 def test_prover_handles_do_not_leak(pkg):
