@@ -1,5 +1,7 @@
+"""Development probe: lsr_lwe_commit_rows_device / lsr_lwe_verify_rows_device captured into HIP graphs (torch.cuda.graph) and replayed
+several times, at n = 4096 (tile pipeline) and n = 2^16 (fused pipeline).  Found the captured-hipMemsetAsync problem (profiles/README.md)."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
 pkg = entry.load_package()
 q, n, k, batch, msg_len = 17592169062401, 4096, 2, 12, 9
