@@ -65,6 +65,12 @@ size_t lsr_gaussian_cdf(double sigma, uint64_t* cdf, size_t cap) LSR_NOEXCEPT;
  * derived from it — reproducible contexts for tests and for replicating ONE context on several devices; such a context is
  * only as secret as the 64-bit seed.  key_seed == 0: 256-bit OS entropy, exactly lwe_context_create. */
 LweContext* lsr_lwe_context_create_seeded(const PublicParams* params, uint64_t key_seed, int device) LSR_NOEXCEPT;
+/* The modulus to put into PublicParams.modulus for a context whose lwe_linear_combine has the reference's range
+ * (commitment.cpp:88-96,247-266: any coefficient below the plaintext modulus): the largest 60-bit prime = 1 (mod 2 ring_degree).
+ * A default context (any modulus no transform can use: 2^44 + 1, 12289 ...) commits under a 44-bit prime on the FP64 kernels and
+ * refuses combinations whose centred coefficients sum beyond ~800 (noise budget); under the 60-bit prime the bound is ~2^25 and
+ * the u64 Harvey/Shoup kernels run (about 1.5x the time per transform).  0 for an unsupported ring_degree. */
+uint64_t lsr_lwe_wide_modulus(uint32_t ring_degree) LSR_NOEXCEPT;
 uint64_t lsr_lwe_modulus(const LweContext* ctx) LSR_NOEXCEPT;         /* internal q actually used */
 uint64_t lsr_lwe_plain_modulus(const LweContext* ctx) LSR_NOEXCEPT;   /* t */
 uint32_t lsr_lwe_ring_degree(const LweContext* ctx) LSR_NOEXCEPT;

@@ -399,6 +399,11 @@ class Commitment:
     __del__ = free
 
 
+def wide_modulus(ring_degree):
+    """``lsr_lwe_wide_modulus``: the 60-bit NTT prime to pass as ``Params.q`` for reference-range linear combinations."""
+    return int(_abi.lib().lsr_lwe_wide_modulus(int(ring_degree)))
+
+
 def words_to_limbs(words, limb_bits=16, limbs_per_word=4):
     """``lsr_words_to_limbs``: little-endian limbs of field elements wider than the plaintext modulus, so that a commitment
     binds them in full (a message word >= t is embedded mod t and never opens — commitment.cpp:152,223-226)."""

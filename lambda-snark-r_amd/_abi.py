@@ -129,6 +129,7 @@ SIGNATURES = {
     "lsr_lwe_commit_rows_device": (c_int, [vp, vp, c_size, c_size, vp, vp, vp]),
     "lsr_lwe_verify_rows_device": (c_int, [vp, vp, vp, c_size, c_size, vp, vp]),
     "lsr_lwe_pipeline": (ctypes.c_char_p, [vp]),
+    "lsr_lwe_wide_modulus": (ctypes.c_uint64, [ctypes.c_uint32]),
     "lsr_minimal_primitive_root": (u64, [u64, u32]),
     # r1cs.h (SEAL/NTL-free shim, host only)
     "lambda_snark_r1cs_create": (c_int, [ctypes.POINTER(SparseMatrix), ctypes.POINTER(SparseMatrix), ctypes.POINTER(SparseMatrix), u64, ctypes.POINTER(vp)]),

@@ -1236,6 +1236,10 @@ LweContext* lsr_lwe_context_create_seeded(const PublicParams* params, uint64_t k
 
 void lwe_context_free(LweContext* ctx) noexcept { lsr::destroy_lwe_context(ctx); }
 
+uint64_t lsr_lwe_wide_modulus(uint32_t ring_degree) noexcept {
+    if (ring_degree < 2 || (ring_degree & (ring_degree - 1)) != 0 || ring_degree > 131072) return 0;
+    return lsr::largest_prime_congruent_one(2ull * ring_degree, 60);
+}
 uint64_t lsr_lwe_modulus(const LweContext* ctx) noexcept { return ctx ? ctx->q : 0; }
 uint64_t lsr_lwe_plain_modulus(const LweContext* ctx) noexcept { return ctx ? ctx->t : 0; }
 uint32_t lsr_lwe_ring_degree(const LweContext* ctx) noexcept { return ctx ? ctx->n : 0; }

@@ -583,6 +583,19 @@ def test_large_combination_coefficients_need_a_wide_modulus(pkg, oracle):
     assert pkg.verify_opening_with_context(wide, comb, expect)
     assert not pkg.verify_opening_with_context(wide, comb, [expect[0] + 1] + expect[1:])
     wide.close()
+    # the library names such a prime itself (lsr_lwe_wide_modulus): sixteen terms with coefficients all over [0, t) — the reference's
+    # own range (commitment.cpp:247-266) — combine and open, word for word the oracle's combination
+    q60 = pkg.wide_modulus(4096)
+    assert 2**59 < q60 < 2**60 and (q60 - 1) % 8192 == 0 and oracle.L.oracle_is_prime(q60) == 1 and q60 == oracle.L.oracle_largest_prime_1mod(8192, 60) and pkg.wide_modulus(4097) == 0
+    rng = np.random.default_rng(60)
+    many = [[int(x) for x in rng.integers(0, t, 6)] for _ in range(16)]
+    cs = [int(x) for x in rng.integers(0, t, 16)]
+    ctx60 = pkg.LweContext(pkg.Params(q=q60, n=4096, k=2, sigma=3.19), key_seed=6)
+    assert ctx60.commit_modulus == q60
+    coms = [pkg.Commitment(ctx60, m, seed=100 + i) for i, m in enumerate(many)]
+    comb = pkg.Commitment.linear_combine(ctx60, coms, cs)
+    assert pkg.verify_opening_with_context(ctx60, comb, [sum(c * m[i] for c, m in zip(cs, many)) % t for i in range(6)])
+    ctx60.close()
     narrow = pkg.LweContext(pkg.Params(q=17592186044417, n=4096, k=2, sigma=3.19), key_seed=5)
     coms = [pkg.Commitment(narrow, m, seed=10 + i) for i, m in enumerate(msgs)]
     small = pkg.Commitment.linear_combine(narrow, coms, [200, 300, 200])
