@@ -100,6 +100,7 @@ __device__ __forceinline__ void buf_store64(rsrc_t r, uint32_t lane_bytes, uint3
 }
 
 struct ArithF64 {
+    static constexpr bool kUnitTopTwiddles = false;   // (cyclic F64 / u64 contexts exist, but only the Goldilocks kernels are product-bound)
     using elem = double;     // residue (exact integer in a double)
     using twid = double;     // twiddle (canonical, as double)
 
@@ -179,6 +180,7 @@ __device__ __forceinline__ uint64_t mul_shoup_lazy(uint64_t x, ShoupOperand o, u
 }
 
 struct ArithU64 {
+    static constexpr bool kUnitTopTwiddles = false;   // (cyclic F64 / u64 contexts exist, but only the Goldilocks kernels are product-bound)
     using elem = uint64_t;
     using twid = ShoupOperand;
 
@@ -311,6 +313,21 @@ struct ArithGold {
         const uint64_t a = x, b = y;
         x = gold_add(a, b);
         y = gold_mul_mont(gold_sub(a, b), w);
+    }
+    // butterflies whose twiddle is omega^0 = 1 (the u = 0 groups of a cyclic transform's top round, lsr_ntt_kernels.hpp): no product
+    static constexpr bool kUnitTopTwiddles = true;          // Goldilocks contexts are cyclic (lsr_ntt.hip build_context)
+    static __device__ __forceinline__ void ct_unit(elem& x, elem& y, const ModParams&) {
+        const uint64_t a = x, t = y >= kGoldilocks ? y - kGoldilocks : y;      // ct's sums need a canonical second operand
+        unsigned long long s, d;
+        const bool carry = __builtin_uaddll_overflow(a, t, &s);
+        const bool borrow = __builtin_usubll_overflow(a, t, &d);
+        x = s + (carry ? kGoldEpsilon : 0ull);
+        y = d - (borrow ? kGoldEpsilon : 0ull);
+    }
+    static __device__ __forceinline__ void gs_unit(elem& x, elem& y, const ModParams&) {
+        const uint64_t a = x, b = y;
+        x = gold_add(a, b);
+        y = gold_sub(a, b);
     }
     static __device__ __forceinline__ void gs_scaled(elem& x, elem& y, twid w_scaled, twid n_inv, const ModParams&) {
         const uint64_t a = x, b = y;

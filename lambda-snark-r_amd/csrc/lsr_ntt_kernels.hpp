@@ -110,7 +110,10 @@ __device__ __forceinline__ void load_round_twiddles(typename A::twid (&w)[kRound
 }
 
 // ---- butterflies of one round, forward (Cooley–Tukey, high bit first) -----------------------------
-template <class A, int LO, int R>
+// TOP: the round holds the transform's first stages (group index 0 above it).  Flavours with A::kUnitTopTwiddles (cyclic tables:
+// entry m + 0 of every stage is omega^0 = 1, lsr_host_math.cpp build_cyclic_twiddles) then skip the product of the u = 0 butterflies —
+// 15 of the 32 butterflies of a radix-16 top round, 15.6 % of a 4096-point transform's products.
+template <class A, int LO, int R, bool TOP = false>
 __device__ __forceinline__ void forward_round(typename A::elem (&v)[kRegs], const typename A::twid (&w)[kRoundTwiddles], const ModParams& p) {
     constexpr int G = 1 << (4 - R);
     int slot = 0;
@@ -125,7 +128,12 @@ __device__ __forceinline__ void forward_round(typename A::elem (&v)[kRegs], cons
 #pragma unroll
                 for (int l = 0; l < half; ++l) {
                     const int kx = (g << R) | (u << (j + 1)) | l;
-                    A::ct(v[kx], v[kx + half], tw, p);
+                    if constexpr (TOP && A::kUnitTopTwiddles) {
+                        if (u == 0) A::ct_unit(v[kx], v[kx + half], p);
+                        else A::ct(v[kx], v[kx + half], tw, p);
+                    } else {
+                        A::ct(v[kx], v[kx + half], tw, p);
+                    }
                 }
             }
         }
@@ -155,7 +163,12 @@ __device__ __forceinline__ void inverse_round(typename A::elem (&v)[kRegs], cons
 #pragma unroll
                 for (int l = 0; l < half; ++l) {
                     const int kx = (g << R) | (u << (j + 1)) | l;
-                    A::gs(v[kx], v[kx + half], tw, p);
+                    if constexpr (FINAL && A::kUnitTopTwiddles) {      // the last round = the forward transform's top round: u = 0 is omega^0
+                        if (u == 0) A::gs_unit(v[kx], v[kx + half], p);
+                        else A::gs(v[kx], v[kx + half], tw, p);
+                    } else {
+                        A::gs(v[kx], v[kx + half], tw, p);
+                    }
                 }
             }
         }
@@ -261,7 +274,7 @@ __device__ __forceinline__ void tile_forward_body(uint64_t* __restrict__ data, s
             constexpr int LO1 = TileRound<LT, I + 1>::LO, R1 = TileRound<LT, I + 1>::R;
             load_round_twiddles<A, LO1, R1, false, false>(w[(I + 1) & 1], lane_base<LO1, R1>(t), block_pos, nmask, p.logn, table);
         }
-        forward_round<A, LO, R>(v, w[I & 1], p);
+        forward_round<A, LO, R, I == 0 && !RAW_IN && (LO + R == LT)>(v, w[I & 1], p);   // !RAW_IN: this pass is the whole transform (LT = log n)
         uint64_t* const row = lds + lds_slot(base);
 #pragma unroll
         for (int k = 0; k < kRegs; ++k) row[lds_slot(reg_offset<LO, R>(k))] = elem_bits<A>(v[k]);
