@@ -170,8 +170,11 @@ def test_seeded_sampler_bit_exact(pkg, oracle, sigma, length):
 # ---- bit-exactness against the oracle -------------------------------------------------------------------
 @pytest.mark.parametrize("q,n,k", [(12289, 4096, 2), (17592186044417, 4096, 2), (12289, 256, 2), (17592186044417, 1024, 4),
                                    (1152921504606584833, 4096, 1), (12289, 8192, 3), (12289, 512, 5), (1152921504606584833, 256, 7),
-                                   (12289, 2, 1), (12289, 64, 16), (12289, 131072, 1)])
+                                   (12289, 2, 1), (12289, 64, 16), (12289, 131072, 1), ("wide", 65536, 2), ("wide", 1024, 3)])
 def test_commit_bit_exact_vs_oracle(pkg, oracle, q, n, k):
+    if q == "wide":                                            # the 60-bit prime the library names for reference-range combinations
+        q = pkg.wide_modulus(n)
+        assert q == oracle.L.oracle_largest_prime_1mod(2 * n, 60)
     lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=KEY)
     oq, a_hat = oracle.lwe_public_matrix(q, n, k, 3.19, KEY)
     assert lctx.commit_modulus == oq
