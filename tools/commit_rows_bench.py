@@ -19,6 +19,8 @@ lib = pkg._abi.lib()
 N, K = int(os.environ.get("N", 4096)), int(os.environ.get("K", 2))
 J, MSG, REPS = int(os.environ.get("J", 16384)), int(os.environ.get("MSG", 16)), int(os.environ.get("REPS", 10))
 Q = 17592169062401 if N <= 4096 else 0
+if os.environ.get("WIDE") == "1":          # the 60-bit prime for reference-range linear combinations (general kernels, u64 flavour)
+    Q = int(lib.lsr_lwe_wide_modulus(N))
 
 
 def make(fused):
