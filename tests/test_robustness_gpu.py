@@ -58,6 +58,65 @@ def test_threads_committing_on_one_context(pkg, oracle):
     assert not errors
 
 
+def test_threads_mixing_asynchronous_and_synchronous_calls_on_one_context(pkg, oracle):
+    """Three kinds of caller on ONE context at the same time: threads that enqueue lsr_lwe_commit_rows_device / lsr_lwe_verify_rows_device
+    on streams of their own and synchronise only those streams, threads that derive keys on the device, and threads in the
+    synchronous lwe_commit / lwe_verify_opening.  The context orders them (mutex for the enqueue, last-use event for the
+    workspaces): every row equals the reference rows, every opening succeeds, every single commitment equals the oracle's."""
+    import torch
+    q, n, k, batch, msg_len = 17592186044417, 4096, 2, 64, 7
+    lctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=41)
+    rng = np.random.default_rng(41)
+    msgs = rng.integers(0, lctx.plain_modulus, size=(batch, msg_len), dtype=np.uint64)
+    seeds = rng.integers(1, 2**63, size=batch, dtype=np.uint64)
+    keys = lctx.commit_keys(msgs, seeds)
+    d_msgs = torch.from_numpy(msgs.view(np.int64)).cuda(); d_keys = torch.from_numpy(keys.view(np.int64)).cuda()
+    words = lctx.commitment_words
+    ref = torch.zeros((batch, words), dtype=torch.int64, device="cuda")
+    lctx.commit_rows_device(d_msgs.data_ptr(), msg_len, batch, d_keys.data_ptr(), ref.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    errors = []
+
+    def rows_worker(i):
+        st = torch.cuda.Stream()
+        rows = torch.zeros((batch, words), dtype=torch.int64, device="cuda")
+        res = torch.zeros(batch, dtype=torch.int32, device="cuda")
+        for it in range(15):
+            rows.zero_(); res.zero_()
+            torch.cuda.current_stream().synchronize()
+            lctx.commit_rows_device(d_msgs.data_ptr(), msg_len, batch, d_keys.data_ptr(), rows.data_ptr(), st.cuda_stream)
+            lctx.verify_rows_device(rows.data_ptr(), d_msgs.data_ptr(), msg_len, batch, res.data_ptr(), st.cuda_stream)
+            st.synchronize()
+            if not torch.equal(rows, ref) or int(res.sum().item()) != batch:
+                errors.append(("rows", i, it))
+
+    def keys_worker(i):
+        st = torch.cuda.Stream()
+        out = torch.zeros((batch, 4), dtype=torch.int64, device="cuda")
+        for it in range(15):
+            out.zero_()
+            torch.cuda.current_stream().synchronize()
+            lctx.commit_keys_device(d_msgs.data_ptr(), msg_len, seeds, out.data_ptr(), st.cuda_stream)
+            st.synchronize()
+            if not torch.equal(out, d_keys):
+                errors.append(("keys", i, it))
+
+    def single_worker(i):
+        for it in range(10):
+            j = (7 * i + it) % batch
+            c = pkg.Commitment(lctx, [int(x) for x in msgs[j]], int(seeds[j]))
+            if not np.array_equal(c.as_words().view(np.int64), ref[j].cpu().numpy()) or not pkg.verify_opening_with_context(lctx, c, [int(x) for x in msgs[j]]):
+                errors.append(("single", i, it))
+
+    threads = ([threading.Thread(target=rows_worker, args=(i,)) for i in range(2)] + [threading.Thread(target=keys_worker, args=(i,)) for i in range(1)] +
+               [threading.Thread(target=single_worker, args=(i,)) for i in range(2)])
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert np.array_equal(ref[3].cpu().numpy().view(np.uint64), oracle.lwe_commit(q, n, k, 3.19, 41, [int(x) for x in msgs[3]], int(seeds[3])))
+    lctx.close()
+    assert not errors, errors[:5]
+
+
 def test_no_device_memory_growth(pkg):
     import torch
     torch.cuda.synchronize()
