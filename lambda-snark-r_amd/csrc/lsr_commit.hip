@@ -346,6 +346,16 @@ constexpr size_t kSampledChunkBytes = size_t(LSR_SAMPLED_CHUNK_MIB) << 20;   // 
 #endif
 constexpr size_t kFullCommitChunkBytes = size_t(LSR_FULL_CHUNK_MIB) << 20;   // full commitments at n >= 2^16: witness workspace per chunk
 constexpr int kFusedStreams = LSR_FUSED_STREAMS;                          // chunk lanes of the three-launch schedule (lane 0 = the caller's stream)
+#ifndef LSR_VERIFY_CHUNK_MIB
+#define LSR_VERIFY_CHUNK_MIB 128
+#endif
+#ifndef LSR_VERIFY_STREAMS
+#define LSR_VERIFY_STREAMS 2
+#endif
+// (tools/verify_sweep.sh, 1024 openings at n = 2^16, k = 4: one lane x 128 MiB 1.77 ms, two lanes x 64 / 128 / 192 / 256 MiB 1.70 / 1.62 / 1.70 / 1.73 ms,
+// three lanes x 64 MiB 1.73 ms)
+constexpr size_t kVerifyChunkBytes = size_t(LSR_VERIFY_CHUNK_MIB) << 20;  // openings at n >= 2^16: workspace of the u vectors per chunk
+constexpr int kVerifyStreams = LSR_VERIFY_STREAMS;                        // chunk lanes of the openings (lane 0 = the caller's stream)
 
 template <int K>
 static void launch_mid(const LweContext& c, const uint64_t* ws, uint64_t* d_u, size_t vectors, hipStream_t s) {
@@ -920,30 +930,39 @@ static void verify_rows_device(const LweContext& c, const uint64_t* d_rows, cons
     }
     if (c.s_perm.ptr && c.a_perm.ptr) {     // n = 2^16 / 2^17: three launches per chunk, u read once, v read once (lsr_commit_tile.hpp)
         const size_t vec_words = (size_t)k << c.logn;
-        const size_t chunk = std::max<size_t>(1, kFusedChunkBytes / (vec_words * 8));
+        const size_t chunk = std::max<size_t>(1, kVerifyChunkBytes / (vec_words * 8));
         const size_t slot = std::min(chunk, count);
-        if (c.ws_mid.count < slot * (vec_words + n)) c.ws_mid.allocate(slot * (vec_words + n));
+        // chunk lanes like the commitments' (commit_rows_fused): a chunk's three launches are a dependent chain whose fills and drains
+        // the other lane's kernels cover (one lane: 1.84 ms per 1024 openings at rank 4, neither memory nor FP64 half busy)
+        const int streams = static_cast<int>(std::min<size_t>((size_t)kVerifyStreams, (count + chunk - 1) / chunk));
+        ensure_side_streams(c, streams);
+        const size_t slot_words = slot * (vec_words + n);
+        if (c.ws_mid.count < slot_words * streams) c.ws_mid.allocate(slot_words * streams);
         const RoundConsts<ArithF64> cs{c.ntt->n_inv_f64, c.ntt->w_last_scaled_f64};
         const int r = c.logn - 12, lo = 12;
-        for (size_t first = 0; first < count; first += chunk) {
+        fork_lanes(c, s, streams);                    // behind the clear of the verdict state above
+        size_t index = 0;
+        for (size_t first = 0; first < count; first += chunk, ++index) {
             const size_t now = std::min(chunk, count - first);
-            uint64_t* const ws = c.ws_mid.ptr;
-            uint64_t* const ws_out = c.ws_mid.ptr + slot * vec_words;
+            hipStream_t st = index % streams == 0 ? s : c.side[index % streams - 1];
+            uint64_t* const ws = c.ws_mid.ptr + (index % streams) * slot_words;
+            uint64_t* const ws_out = ws + slot * vec_words;
             const VerifyTopJob job{d_rows + first * row, ws, ws_out, d_msgs + first * msg_len, (uint64_t)msg_len, (uint64_t)row, c.ws_vflags.ptr + first,
                                    c.ws_vbad + first, (uint32_t)now, k, c.q, c.t};
             const unsigned grid_f = static_cast<unsigned>((now * k << c.logn) >> (r + 8)), grid_i = static_cast<unsigned>((now << c.logn) >> (r + 8));
-            if (r == 4) hipLaunchKernelGGL((verify_top_forward_kernel<4>), dim3(grid_f), dim3(256), 0, s, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
-            else hipLaunchKernelGGL((verify_top_forward_kernel<5>), dim3(grid_f), dim3(256), 0, s, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
+            if (r == 4) hipLaunchKernelGGL((verify_top_forward_kernel<4>), dim3(grid_f), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
+            else hipLaunchKernelGGL((verify_top_forward_kernel<5>), dim3(grid_f), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->fwd_f64.ptr);
             switch (k) {
-                case 1: launch_mid_general<1, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, s); break;
-                case 2: launch_mid_general<2, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, s); break;
-                case 3: launch_mid_general<3, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, s); break;
-                default: launch_mid_general<4, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, s); break;
+                case 1: launch_mid_general<1, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, st); break;
+                case 2: launch_mid_general<2, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, st); break;
+                case 3: launch_mid_general<3, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, st); break;
+                default: launch_mid_general<4, 1>(c, ws, vec_words, ws_out, n, c.s_perm.ptr, now, st); break;
             }
-            if (r == 4) hipLaunchKernelGGL((verify_top_inverse_kernel<4>), dim3(grid_i), dim3(256), 0, s, job, lo, c.ntt->mod, c.ntt->inv_f64.ptr, cs);
-            else hipLaunchKernelGGL((verify_top_inverse_kernel<5>), dim3(grid_i), dim3(256), 0, s, job, lo, c.ntt->mod, c.ntt->inv_f64.ptr, cs);
+            if (r == 4) hipLaunchKernelGGL((verify_top_inverse_kernel<4>), dim3(grid_i), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->inv_f64.ptr, cs);
+            else hipLaunchKernelGGL((verify_top_inverse_kernel<5>), dim3(grid_i), dim3(256), 0, st, job, lo, c.ntt->mod, c.ntt->inv_f64.ptr, cs);
             LSR_HIP(hipGetLastError());
         }
+        join_lanes(c, s, streams);
         return;
     }
     // general form: split the rows (header and canonicity checks on the way), transform, product, subtract, inverse, decode

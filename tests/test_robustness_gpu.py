@@ -312,6 +312,41 @@ def test_commit_rows_are_graph_capturable_and_leave_the_context_usable(pkg, orac
     ctx.close()
 
 
+def test_chunk_lanes_are_graph_capturable(pkg):
+    """n = 2^16: commitments and openings run their chunks on two lanes (the caller's stream and a side stream of the context, forked
+    and joined with events).  Captured into a HIP graph the lanes become branches of the graph; 300 rank-1 rows = three chunks of
+    commitments and two of openings.  Two replays: rows equal the eagerly computed ones, every opening succeeds."""
+    import torch
+    q, n, k, batch, msg_len = 17592182243329, 65536, 1, 300, 4
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=3.19), key_seed=0xFACE)
+    assert ctx.pipeline == "fused"
+    rng = np.random.default_rng(12)
+    msgs = rng.integers(0, ctx.plain_modulus, size=(batch, msg_len), dtype=np.uint64)
+    seeds = rng.integers(1, 2**63, size=batch, dtype=np.uint64)
+    keys = ctx.commit_keys(msgs, seeds)
+    d_msgs = torch.from_numpy(msgs.view(np.int64)).cuda(); d_keys = torch.from_numpy(keys.view(np.int64)).cuda()
+    rows = torch.zeros((batch, ctx.commitment_words), dtype=torch.int64, device="cuda")
+    res = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    both = lambda st: (ctx.commit_rows_device(d_msgs.data_ptr(), msg_len, batch, d_keys.data_ptr(), rows.data_ptr(), st),
+                       ctx.verify_rows_device(rows.data_ptr(), d_msgs.data_ptr(), msg_len, batch, res.data_ptr(), st))
+    with torch.cuda.stream(side):
+        both(side.cuda_stream)
+    side.synchronize()
+    want = rows.clone()
+    assert int(res.sum().item()) == batch
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        both(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        rows.zero_(); res.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(rows, want) and int(res.sum().item()) == batch
+    ctx.close()
+
+
 def test_prover_handles_do_not_leak(pkg):
     import torch
     rng = np.random.default_rng(8)
