@@ -397,3 +397,24 @@ def test_long_message_batches_derive_their_keys_on_the_device(pkg, oracle):
     keep = np.arange(batch) != 7
     assert np.array_equal(rows0[keep], rows[keep]) and not np.array_equal(rows0[7], rows[7])
     ctx.close()
+
+
+@pytest.mark.parametrize("q,n,k,batch", [("wide", 1024, 3, 80), (12289, 512, 5, 140), (17592182243329, 65536, 2, 3)])
+def test_long_message_batches_on_every_pipeline(pkg, oracle, q, n, k, batch):
+    """The device key derivation sits in the staging of the host entry points, in front of whichever pipeline the context takes: the
+    general kernels (60-bit modulus on the u64 flavour; rank 5), and the fused pipeline at n = 2^16.  Full-length messages, flat batch
+    against the oracle and against a single lwe_commit (host derivation)."""
+    if q == "wide":
+        q = pkg.wide_modulus(n)
+    ctx = pkg.LweContext(pkg.Params(q=q, n=n, k=k, sigma=SIGMA), key_seed=KEY)
+    assert batch * n >= 2**16
+    rng = np.random.default_rng(n + k)
+    msgs = rng.integers(0, min(ctx.plain_modulus, ctx.modulus()), size=(batch, n), dtype=np.uint64)   # (the wrapper reduces mod params.modulus, commitment.rs:33-36)
+    seeds = rng.integers(1, 2**64, size=batch, dtype=np.uint64)
+    rows = pkg.Commitment.batch_words(ctx, msgs, seeds)
+    for j in (0, batch - 1):
+        assert np.array_equal(rows[j], oracle.lwe_commit(q, n, k, SIGMA, KEY, [int(x) for x in msgs[j]], int(seeds[j]))), j
+    single = pkg.Commitment(ctx, [int(x) for x in msgs[1]], int(seeds[1]))
+    assert np.array_equal(single.as_words(), rows[1])
+    assert pkg.verify_openings_words(ctx, rows, msgs) == [1] * batch
+    ctx.close()
