@@ -41,7 +41,7 @@ def report(what, **kw):
 
 while time.time() < deadline:
     cases += 1
-    which = rng.integers(0, 14)
+    which = rng.integers(0, 15)
     if which < 5:            # negacyclic transforms, both flavours
         logn = int(rng.integers(1, 18)); n = 1 << logn
         bits = int(rng.integers(max(logn + 3, 14), 61))
@@ -206,6 +206,26 @@ while time.time() < deadline:
         want = np.ones(batch, dtype=np.int32); want[victim] = 0
         if not np.array_equal(res.cpu().numpy(), want): report("verify rows", n=n, k=k, batch=batch, vl=vl, victim=victim)
         ctx.close(); del d_rows, d_msgs, d_keys
+    elif which == 14:        # per-commitment keys derived on the device = the host derivation; long flat batches (device keys behind the host call)
+        import torch
+        n = 1 << int(rng.integers(3, 13)); k = int(rng.integers(1, 4))
+        seed_key = int(rng.integers(1, 2**62))
+        ctx = pkg.LweContext(pkg.Params(q=17592186044417, n=n, k=k, sigma=3.19), key_seed=seed_key)
+        ml = int(rng.integers(0, n + 40)); batch = int(rng.integers(1, 300))
+        msgs = rng.integers(0, 2**64, size=(batch, ml), dtype=np.uint64) if rng.integers(0, 2) else rng.integers(0, ctx.plain_modulus, size=(batch, ml), dtype=np.uint64)
+        seeds = rng.integers(1, 2**64, size=batch, dtype=np.uint64)
+        want = ctx.commit_keys(msgs, seeds)
+        d_msgs = torch.from_numpy(msgs.view(np.int64)).cuda() if ml else None
+        d_keys = torch.zeros((batch, 4), dtype=torch.int64, device="cuda")
+        ctx.commit_keys_device(d_msgs.data_ptr() if ml else None, ml, seeds, d_keys.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if not np.array_equal(d_keys.cpu().numpy().view(np.uint64), want): report("device keys", n=n, k=k, ml=ml, batch=batch)
+        if ml and batch * min(ml, n) >= 2**16:
+            small = msgs % np.uint64(ctx.plain_modulus)
+            rows = pkg.Commitment.batch_words(ctx, small, seeds)
+            j = int(rng.integers(0, batch))
+            if not np.array_equal(rows[j], orc.lwe_commit(17592186044417, n, k, 3.19, seed_key, small[j], int(seeds[j]))): report("long flat batch", n=n, k=k, ml=ml, batch=batch, j=j)
+        ctx.close()
     else:                    # commitments
         n = 1 << int(rng.integers(1, 13)); k = int(rng.integers(1, 5))
         q = [12289, 17592186044417, 17592169062401, prime_for(n, int(rng.integers(41, 61)))][int(rng.integers(0, 4))]
