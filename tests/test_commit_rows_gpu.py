@@ -307,11 +307,12 @@ def test_asynchronous_calls_on_one_context_are_ordered(pkg):
     assert torch.equal(rows, want)
 
 
-@pytest.mark.parametrize("n,k,msg_len", [(4096, 2, 0), (4096, 2, 1), (4096, 2, 5), (4096, 2, 255), (4096, 2, 256), (4096, 2, 257), (4096, 2, 1000),
+@pytest.mark.parametrize("n,k,msg_len", [(4096, 2, 0), (4096, 2, 1), (4096, 2, 5), (4096, 2, 63), (4096, 2, 64), (4096, 2, 65), (4096, 2, 129), (4096, 2, 255),
+                                         (4096, 2, 256), (4096, 2, 257), (4096, 2, 1000),
                                          (4096, 2, 4096), (4096, 2, 5000), (1024, 1, 1024), (65536, 4, 3000)])
 def test_device_key_derivation_equals_the_host_one(pkg, oracle, n, k, msg_len):
     """lsr_lwe_commit_keys_device = lsr_lwe_commit_keys word for word (the keys ARE the commitment's randomness, so a single differing
-    bit changes every row): message lengths around the 256-lane stride of the hash, full length, beyond the ring degree (only the
+    bit changes every row): message lengths around the 64-lane stride of the hash (and the 256 of its first version), full length, beyond the ring degree (only the
     first n words are embedded, commitment.cpp:146-149), message words >= t up to 2^64 - 1; then the rows made from the device's
     keys against the CPU oracle's lwe_commit."""
     import torch
