@@ -99,11 +99,31 @@ StreamKey derive_commit_key(uint64_t seed, const uint32_t id[4], const uint64_t*
     const StreamKey base{{(uint32_t)seed, (uint32_t)(seed >> 32), kTagLsr2, kTagCommit, id[0], id[1], id[2], id[3]}};
     const StreamKey points = kdf(base, kTagHashPoints, 0, 0, 0);
     const uint64_t x1 = point61(points.w[0], points.w[1]), x2 = point61(points.w[2], points.w[3]);
-    uint64_t h1 = 0, h2 = 0, p1 = x1, p2 = x2;
-    for (size_t i = 0; i < copy; ++i) {
-        const uint64_t m = message[i] % t;
-        h1 += mul61(m, p1); if (h1 >= kP61) h1 -= kP61;
-        h2 += mul61(m, p2); if (h2 >= kP61) h2 -= kP61;
+    // h_a = sum_i m_i x_a^(i+1), evaluated as four interleaved Horner chains in y = x^4 per point (one product per word and point, eight
+    // independent chains for the multiplier's pipeline; the running-power form of round 2 spent two dependent products per word and
+    // point: 10 us per full-length message, now about half): h = sum_r x^(r+1) H_r(y), H_r(y) = sum_j m_(4j+r) y^j
+    auto reduce = [t](uint64_t w) { return w < t ? w : w % t; };
+    const uint64_t y1 = mul61(mul61(x1, x1), mul61(x1, x1)), y2 = mul61(mul61(x2, x2), mul61(x2, x2));
+    uint64_t a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    size_t i = copy;
+    while (i % 4 != 0) {                                    // the ragged top: residues r = i mod 4 that own one word more
+        --i;
+        a1[i % 4] = reduce(message[i]);
+        a2[i % 4] = a1[i % 4];
+    }
+    while (i >= 4) {
+        i -= 4;
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t m = reduce(message[i + r]);
+            uint64_t v1 = mul61(a1[r], y1) + m, v2 = mul61(a2[r], y2) + m;
+            a1[r] = v1 >= kP61 ? v1 - kP61 : v1;
+            a2[r] = v2 >= kP61 ? v2 - kP61 : v2;
+        }
+    }
+    uint64_t h1 = 0, h2 = 0, p1 = x1, p2 = x2;             // x^(r+1)
+    for (int r = 0; r < 4; ++r) {
+        h1 += mul61(a1[r], p1); if (h1 >= kP61) h1 -= kP61;
+        h2 += mul61(a2[r], p2); if (h2 >= kP61) h2 -= kP61;
         p1 = mul61(p1, x1);
         p2 = mul61(p2, x2);
     }
