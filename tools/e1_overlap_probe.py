@@ -12,7 +12,7 @@ r = torch.randint(0, Q, (J, K, N), dtype=torch.int64, device="cuda")
 e1 = torch.randint(0, 8, (J, K, N), dtype=torch.int64, device="cuda")
 u = torch.empty_like(r); e1b = torch.empty_like(r)
 seeds = np.arange(1, J + 1, dtype=np.uint64)
-main = torch.cuda.current_stream(); s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+main = torch.cuda.current_stream(); s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(priority=int(os.environ.get("PRIO", "0")))
 def commit(): assert lib.lsr_mlwe_matvec_batch_device(a.handle, r.data_ptr(), e1.data_ptr(), u.data_ptr(), J, None, s1.cuda_stream) == 0
 def sample(): assert lib.lsr_lwe_sample_blinding_device(b.handle, e1b.data_ptr(), J, seeds.ctypes.data, s2.cuda_stream) == 0
 def fused(): assert lib.lsr_mlwe_matvec_batch_device(a.handle, r.data_ptr(), None, u.data_ptr(), J, seeds.ctypes.data, s1.cuda_stream) == 0
