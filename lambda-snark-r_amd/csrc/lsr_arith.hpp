@@ -329,10 +329,17 @@ struct ArithGold {
         x = gold_add(a, b);
         y = gold_sub(a, b);
     }
+    // (both constants equal to 1 — Montgomery form 2^32 - 1 — is how a context says "leave the n^-1 out": the quotient plan folds that
+    // factor into a table of its own, lsr_prover.hip; a wave-uniform branch, the last stage then costs no product)
     static __device__ __forceinline__ void gs_scaled(elem& x, elem& y, twid w_scaled, twid n_inv, const ModParams&) {
         const uint64_t a = x, b = y;
-        x = gold_mul_mont(gold_add(a, b), n_inv);
-        y = gold_mul_mont(gold_sub(a, b), w_scaled);
+        if (n_inv == kGoldEpsilon && w_scaled == kGoldEpsilon) {
+            x = gold_add(a, b);
+            y = gold_sub(a, b);
+        } else {
+            x = gold_mul_mont(gold_add(a, b), n_inv);
+            y = gold_mul_mont(gold_sub(a, b), w_scaled);
+        }
     }
     static __device__ __forceinline__ void end_of_inverse_round(elem&, const ModParams&) {}
     static constexpr bool kPartialRecentre = false;

@@ -359,7 +359,14 @@ static LsrQuotientPlan* create_plan(uint32_t m, int device) {
             std::vector<uint64_t> twist(m), untwist(m);
             const uint64_t half_m_inv = invmod_prime((2ull * m) % q, q);
             p->half_m_inv = prover_montgomery(half_m_inv);
-            uint64_t up = 1, down = half_m_inv;
+            // The plan's own context transforms WITHOUT the m^-1 of its inverse direction (both scaling constants 1: the last stage then
+            // costs no product, ArithGold::gs_scaled).  A and B reach the coset m times too large, their product and z carry m^2, and the
+            // untwist table takes it back: untwist[p] = (2m)^-1 m^-2 psi^-bitrev(p).  (The context is private to the plan; the cyclic
+            // transforms of lsr_cyclic_ntt_* use contexts of their own.)
+            p->ntt->n_inv_gold = prover_montgomery(1);
+            p->ntt->w_last_scaled_gold = prover_montgomery(1);       // the last stage's twiddle is omega^0
+            const uint64_t m_inv = invmod_prime(m % q, q);
+            uint64_t up = 1, down = mulmod(half_m_inv, mulmod(m_inv, m_inv, q), q);
             for (uint32_t j = 0; j < m; ++j) {
                 twist[bit_reverse(j, p->logm)] = prover_montgomery(up);
                 untwist[bit_reverse(j, p->logm)] = prover_montgomery(down);
