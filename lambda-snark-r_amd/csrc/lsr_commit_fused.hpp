@@ -183,18 +183,23 @@ __device__ __forceinline__ void f8_uniform_twiddles(double (&w)[7], const double
     }
 }
 
-// (re)build the LDS twiddle image for one direction; the caller separates it from its readers with barriers
-__device__ __forceinline__ void f8_fill_twiddles(double* __restrict__ tw_lds, const double* __restrict__ table, uint32_t tile_pos, int logn, uint32_t t) {
+// (re)build the LDS twiddle image for one direction; the caller separates it from its readers with barriers.
+// IN_REGS: the lane's seven multipliers of the last round stay in `mine` (14 VGPRs) instead of 28 KB of LDS — for pipelines with
+// registers to spare and an occupancy that the LDS footprint limits (openings at n = 4096: three workgroups per CU instead of two)
+template <bool IN_REGS = false>
+__device__ __forceinline__ void f8_fill_twiddles(double* __restrict__ tw_lds, const double* __restrict__ table, uint32_t tile_pos, int logn, uint32_t t,
+                                                 double (&mine)[7]) {
     if (t < kF8TwShared) {
         const int b = t < 64 ? 5 : (t < 192 ? 4 : 3);
         const uint32_t e = t < 64 ? t : (t < 192 ? t - 64 : t - 192);
         tw_lds[t] = table[(1u << (logn - 1 - b)) + (tile_pos >> (b + 1)) + e];
     }
     const uint32_t pos0 = tile_pos + f8_base<3>(t);
-    double mine[7];
     f8_uniform_twiddles<3>(mine, table, pos0, logn);
+    if constexpr (!IN_REGS) {
 #pragma unroll
-    for (int s = 0; s < 7; ++s) tw_lds[kF8TwShared + s * kF8Threads + t] = mine[s];
+        for (int s = 0; s < 7; ++s) tw_lds[kF8TwShared + s * kF8Threads + t] = mine[s];
+    }
 }
 
 // last inverse round of a transform whose top index bit lies in this tile (n = 4096: the tile IS the polynomial): the stage of
@@ -244,7 +249,8 @@ static __global__ void __launch_bounds__(256) f8_permute_matrix_kernel(double* _
 // Sink: store(c, x) — output c in the same layout (raw elements, |x| <= q/2 + 1; FULL: |x| < q, fresh products).
 // Both may use workgroup barriers (every lane calls them, in the same order).
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int K, int NC, bool FULL, class Src, class Sink>
+// TW3_REGS: see f8_fill_twiddles (tw_lds then has kF8TwShared entries only).
+template <int K, int NC, bool FULL, class Src, class Sink, bool TW3_REGS = false>
 __device__ __forceinline__ void f8_tile_pipeline(uint32_t tile_pos, Src& src, Sink& sink, const double* __restrict__ mat, const ModParams& p,
                                                  const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw, const RoundConsts<ArithF64>& cs,
                                                  double* __restrict__ tile_lds, double* __restrict__ tw_lds) {
@@ -265,7 +271,8 @@ __device__ __forceinline__ void f8_tile_pipeline(uint32_t tile_pos, Src& src, Si
 #pragma unroll
         for (int k = 0; k < kF8Regs; ++k) acc[c][k] = 0.0;
 
-    f8_fill_twiddles(tw_lds, fwd_tw, tile_pos, p.logn, t);
+    double mine3[7];
+    f8_fill_twiddles<TW3_REGS>(tw_lds, fwd_tw, tile_pos, p.logn, t, mine3);
     double w0[7], w1[7];
     f8_uniform_twiddles<0>(w0, fwd_tw, tile_pos, p.logn);
     f8_uniform_twiddles<1>(w1, fwd_tw, tile_pos + f8_base<1>(wave0), p.logn);
@@ -275,7 +282,10 @@ __device__ __forceinline__ void f8_tile_pipeline(uint32_t tile_pos, Src& src, Si
     const auto tw_r0 = [&](int s_) { return w0[s_]; };
     const auto tw_r1 = [&](int s_) { return w1[s_]; };
     const auto tw_r2 = [&](int s_) { return s_ == 0 ? tw2[e5] : (s_ < 3 ? tw2[64 + e4 + (s_ - 1)] : tw2[192 + e3 + (s_ - 3)]); };
-    const auto tw_r3 = [&](int s_) { return tw3[s_ * kF8Threads]; };
+    const auto tw_r3 = [&](int s_) {
+        if constexpr (TW3_REGS) return mine3[s_];
+        else return tw3[s_ * kF8Threads];
+    };
 #pragma unroll 1
     for (int i = 0; i < K; ++i) {
         double v[kF8Regs];
@@ -348,7 +358,7 @@ __device__ __forceinline__ void f8_tile_pipeline(uint32_t tile_pos, Src& src, Si
 
     // ---- inverse: each output component through the tile ------------------------------------------------------------------
     __syncthreads();                                     // every lane is done with the forward twiddle image
-    f8_fill_twiddles(tw_lds, inv_tw, tile_pos, p.logn, t);
+    f8_fill_twiddles<TW3_REGS>(tw_lds, inv_tw, tile_pos, p.logn, t, mine3);
     f8_uniform_twiddles<0>(w0, inv_tw, tile_pos, p.logn);
     f8_uniform_twiddles<1>(w1, inv_tw, tile_pos + f8_base<1>(wave0), p.logn);
     __syncthreads();

@@ -244,12 +244,20 @@ struct VerifyTileSink {
     }
 };
 
+// (tools/verify_tile_sweep.sh, 16384 openings: multipliers in LDS, 4 waves/SIMD 0.594 / 0.935 / 0.392 ms at k = 2 / 4 / 1; in registers, 4 waves
+// 0.556 / 0.929 / 0.366 ms; in registers, 6 waves 0.560 / 0.897 / 0.378 ms — the gain is the LDS traffic saved, not the third workgroup)
+#ifndef LSR_VERIFY_TILE_WAVES
+#define LSR_VERIFY_TILE_WAVES 6       // wavefronts per SIMD the kernel is compiled for: 6 = three 512-lane workgroups per CU (80 VGPRs)
+#endif
+#ifndef LSR_VERIFY_TILE_TW_REGS
+#define LSR_VERIFY_TILE_TW_REGS 1     // the last round's multipliers in registers: 40 KB of LDS per workgroup instead of 69 KB
+#endif
 template <int K>
-__global__ void __launch_bounds__(kF8Threads, 4) verify_tile_kernel(VerifyTileJob job, const double* __restrict__ s_perm, ModParams p,
-                                                                     const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw,
-                                                                     RoundConsts<ArithF64> cs) {
+__global__ void __launch_bounds__(kF8Threads, LSR_VERIFY_TILE_WAVES) verify_tile_kernel(VerifyTileJob job, const double* __restrict__ s_perm, ModParams p,
+                                                                                         const double* __restrict__ fwd_tw, const double* __restrict__ inv_tw,
+                                                                                         RoundConsts<ArithF64> cs) {
     __shared__ double tile_lds[kF8TileWords];
-    __shared__ double tw_lds[kF8TwShared + kF8TwPrivate];
+    __shared__ double tw_lds[kF8TwShared + (LSR_VERIFY_TILE_TW_REGS ? 0 : kF8TwPrivate)];
     const uint32_t j = blockIdx.x;
     if (j >= job.count) return;
     const size_t row_words = kRowHeaderWords + ((size_t)(K + 1) << 12);
@@ -261,7 +269,7 @@ __global__ void __launch_bounds__(kF8Threads, 4) verify_tile_kernel(VerifyTileJo
     }
     VerifyTileSource<K> src{row, &job.bad[j], job.q};
     VerifyTileSink<K> sink{job, row, job.msgs + (size_t)j * job.msg_len, &job.flags[j], &job.bad[j], p};
-    f8_tile_pipeline<K, 1, true>(0u, src, sink, s_perm, p, fwd_tw, inv_tw, cs, tile_lds, tw_lds);
+    f8_tile_pipeline<K, 1, true, VerifyTileSource<K>, VerifyTileSink<K>, LSR_VERIFY_TILE_TW_REGS != 0>(0u, src, sink, s_perm, p, fwd_tw, inv_tw, cs, tile_lds, tw_lds);
 }
 
 // =================================================================================================================================
