@@ -247,7 +247,8 @@ struct VerifyTileSink {
 // (tools/verify_tile_sweep.sh, 16384 openings: multipliers in LDS, 4 waves/SIMD 0.594 / 0.935 / 0.392 ms at k = 2 / 4 / 1; in registers, 4 waves
 // 0.556 / 0.929 / 0.366 ms; in registers, 6 waves 0.560 / 0.897 / 0.378 ms — the gain is the LDS traffic saved, not the third workgroup)
 #ifndef LSR_VERIFY_TILE_WAVES
-#define LSR_VERIFY_TILE_WAVES 6       // wavefronts per SIMD the kernel is compiled for: 6 = three 512-lane workgroups per CU (80 VGPRs)
+#define LSR_VERIFY_TILE_WAVES 4       // wavefronts per SIMD the kernel is compiled for (6 = three workgroups per CU: 80 VGPRs with two of them
+                                      // spilled, 15 % more traffic per opening for the same speed at k = 2 — PMC, profiles/README.md)
 #endif
 #ifndef LSR_VERIFY_TILE_TW_REGS
 #define LSR_VERIFY_TILE_TW_REGS 1     // the last round's multipliers in registers: 40 KB of LDS per workgroup instead of 69 KB
